@@ -1,0 +1,93 @@
+"""ctypes binding of libcfhip.so (include/cf_hip.h).  No CPU fallback: if the library is missing
+or a call fails, this raises - the product path never silently degrades."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libcfhip.so")
+
+CF_MAX_SRC = 4
+ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, ACT_RAW_AND_SIGDEPTH = 0, 1, 2, 3
+LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
+
+_f = C.c_void_p  # device pointers travel as integers
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("src", _f * CF_MAX_SRC), ("src_c", C.c_int32 * CF_MAX_SRC), ("n_src", C.c_int32),
+                ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32),
+                ("Wo", C.c_int32), ("stride", C.c_int32), ("weight", _f), ("slots", _f),
+                ("bias", _f), ("K_pad", C.c_int32), ("N", C.c_int32), ("N_pad", C.c_int32),
+                ("residual", _f), ("res_stride", C.c_int32), ("out", _f), ("out2", _f),
+                ("out_stride", C.c_int32), ("out_layout", C.c_int32), ("act", C.c_int32)]
+
+
+class DcnArgs(C.Structure):
+    _fields_ = [("x", _f), ("offmask", _f), ("om_stride", C.c_int32), ("B", C.c_int32),
+                ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("weight", _f), ("bias", _f),
+                ("N", C.c_int32), ("N_pad", C.c_int32), ("out", _f), ("out_stride", C.c_int32),
+                ("act", C.c_int32)]
+
+
+class DecodeArgs(C.Structure):
+    _fields_ = [("scores", _f), ("inds", _f), ("classes", _f), ("reg", _f), ("wh", _f),
+                ("depth", _f), ("rot", _f), ("dim", _f), ("amodal", _f), ("att", _f), ("vel", _f),
+                ("B", C.c_int32), ("K", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("out_h", C.c_int32), ("out_w", C.c_int32), ("norm2d", C.c_int32), ("det", _f)]
+
+
+# every symbol include/cf_hip.h declares: (restype, argtypes)
+_i, _d = C.c_int, C.c_double
+SYMBOLS = {
+    "cf_conv2d_fused": (_i, [C.POINTER(ConvArgs), _f]),
+    "cf_dcn_v2_fused": (_i, [C.POINTER(DcnArgs), _f]),
+    "cf_upsample_dw": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
+    "cf_maxpool2x2": (_i, [_f, _f, _i, _i, _i, _i, _f]),
+    "cf_nchw_to_nhwc4": (_i, [_f, _f, _i, _i, _i, _i, _f]),
+    "cf_nhwc_to_nchw": (_i, [_f, _f, _i, _i, _i, _i, _i, _f]),
+    "cf_topk_workspace_bytes": (C.c_size_t, [_i]),
+    "cf_topk_peaks": (_i, [_f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "cf_frustum_assoc": (_i, [_f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, C.c_float, _f, _f, _f]),
+    "cf_pillar_expand": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _i, _i, _d, _d, _d, _f, _f, _f, _f]),
+    "cf_decode_gather": (_i, [C.POINTER(DecodeArgs), _f]),
+    "cf_last_error": (C.c_char_p, []),
+    "cf_abi_version": (_i, []),
+}
+
+_lib = None
+
+
+class CfHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcfhip.so (once).  Raises if it has not been built - there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CfHipError(
+                f"{LIB_PATH} is missing: build it with `python -m centerfusiondetect3d_amd.build` "
+                "(hipcc, gfx950). The CenterFusion forward has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().cf_last_error().decode()
+        raise CfHipError(f"{what} failed with status {status}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

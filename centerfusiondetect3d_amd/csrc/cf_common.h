@@ -1,0 +1,41 @@
+// Shared device/host helpers for libcfhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "cf_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CF_BK 32          // K chunk (floats) staged per main-loop step
+#define CF_LDS_STRIDE 36  // BK + 4: ds_read_b128 of 16 rows hits 16 distinct 4-bank slots
+
+void cf_set_error(const char* fmt, ...);
+
+#define CF_REQUIRE(cond, ...)    \
+  do {                           \
+    if (!(cond)) {               \
+      cf_set_error(__VA_ARGS__); \
+      return CF_EINVAL;          \
+    }                            \
+  } while (0)
+
+static inline int cf_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    cf_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return CF_ELAUNCH;
+  }
+  return CF_OK;
+}
+
+// Bijective remap of the linear workgroup id so that consecutive logical tiles run on ONE XCD
+// (hardware deals workgroups round-robin over the 8 XCDs; each XCD has its own L2).
+__device__ __forceinline__ int cf_xcd_remap(int b, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ float cf_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -1,0 +1,142 @@
+// HBM-bound helpers of the DLA-34 / IDA-up graph: depthwise transposed-conv upsample (+ skip add),
+// 2x2 max-pool and the two layout changes at the module boundary.  All are one-pass streaming
+// kernels: 16 B per lane, channel-innermost (NHWC) so every wave-instruction touches whole lines.
+#include "cf_common.h"
+
+namespace {
+
+// out[b][y][x][c] = sum_{ky,kx} x[b][(y+p-ky)/f][(x+p-kx)/f][c] * w[ky][kx][c]  (+ skip)
+// for the taps where (y+p-ky) and (x+p-kx) are multiples of f and in range; k = 2f, p = f/2, so
+// exactly two ky (and two kx) qualify per output pixel.
+__global__ __launch_bounds__(256) void upsample_dw_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ skip,
+                                                          float* __restrict__ out, int B, int H, int W,
+                                                          int C4, int f) {
+  const int Ho = H * f, Wo = W * f, k = 2 * f, pad = f / 2;
+  const long total = (long)B * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long pix = i / C4;
+    const int xo = (int)(pix % Wo);
+    pix /= Wo;
+    const int yo = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (skip) acc = reinterpret_cast<const f32x4*>(skip)[i];
+    const int ky0 = (yo + pad) % f, kx0 = (xo + pad) % f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ky = ky0 + a * f;
+      const int yi = (yo + pad - ky) / f;
+      if (yi < 0 || yi >= H || ky >= k) continue;
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const int kx = kx0 + bb * f;
+        const int xi = (xo + pad - kx) / f;
+        if (xi < 0 || xi >= W || kx >= k) continue;
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[((long)(b * H + yi) * W + xi) * C4 + c4];
+        const f32x4 ww = reinterpret_cast<const f32x4*>(w)[(ky * k + kx) * C4 + c4];
+        acc += v * ww;
+      }
+    }
+    reinterpret_cast<f32x4*>(out)[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                         int B, int H, int W, int C4) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long total = (long)B * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long pix = i / C4;
+    const int xo = (int)(pix % Wo);
+    pix /= Wo;
+    const int yo = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    const f32x4* p = reinterpret_cast<const f32x4*>(x) + ((long)(b * H + 2 * yo) * W + 2 * xo) * C4 + c4;
+    const f32x4 a = p[0], bq = p[C4], c = p[(long)W * C4], d = p[(long)W * C4 + C4];
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(a[e], bq[e]), fmaxf(c[e], d[e]));
+    reinterpret_cast<f32x4*>(out)[i] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                            int B, int C, long HW) {
+  const long total = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW, pix = i - b * HW;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) v[c] = x[(b * C + c) * HW + pix];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+}
+
+// (B,H,W,c_stride) -> (B,C,H,W): 32-pixel x 32-channel tiles through LDS so both sides coalesce.
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           long HW, int C, int c_stride) {
+  __shared__ float tile[32][33];
+  const long p0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, b = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const long p = p0 + r;
+    const int c = c0 + tx;
+    tile[r][tx] = (p < HW && c < C) ? x[((long)b * HW + p) * c_stride + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const long p = p0 + tx;
+    if (p < HW && c < C) out[((long)b * C + c) * HW + p] = tile[tx][r];
+  }
+}
+
+inline int grid_for(long total) {
+  long g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+}  // namespace
+
+extern "C" int cf_upsample_dw(const float* x, const float* weight, const float* skip, float* out, int B,
+                              int H, int W, int C, int f, void* stream) {
+  CF_REQUIRE(x && weight && out, "cf_upsample_dw: null buffer");
+  CF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "cf_upsample_dw: bad geometry (C=%d)", C);
+  CF_REQUIRE(f >= 2 && f % 2 == 0, "cf_upsample_dw: f=%d must be even (k=2f, pad=f/2)", f);
+  const long total = (long)B * H * f * W * f * (C / 4);
+  hipLaunchKernelGGL(upsample_dw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, weight,
+                     skip, out, B, H, W, C / 4, f);
+  return cf_check_launch("cf_upsample_dw");
+}
+
+extern "C" int cf_maxpool2x2(const float* x, float* out, int B, int H, int W, int C, void* stream) {
+  CF_REQUIRE(x && out, "cf_maxpool2x2: null buffer");
+  CF_REQUIRE(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "cf_maxpool2x2: bad geometry");
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, B, H,
+                     W, C / 4);
+  return cf_check_launch("cf_maxpool2x2");
+}
+
+extern "C" int cf_nchw_to_nhwc4(const float* x, float* out, int B, int C, int H, int W, void* stream) {
+  CF_REQUIRE(x && out, "cf_nchw_to_nhwc4: null buffer");
+  CF_REQUIRE(B > 0 && C >= 1 && C <= 4 && H > 0 && W > 0, "cf_nchw_to_nhwc4: bad geometry (C=%d)", C);
+  const long total = (long)B * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, B,
+                     C, (long)H * W);
+  return cf_check_launch("cf_nchw_to_nhwc4");
+}
+
+extern "C" int cf_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, int C, int c_stride,
+                               void* stream) {
+  CF_REQUIRE(x && out, "cf_nhwc_to_nchw: null buffer");
+  CF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && c_stride >= C, "cf_nhwc_to_nchw: bad geometry");
+  const long HW = (long)H * W;
+  dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, HW, C, c_stride);
+  return cf_check_launch("cf_nhwc_to_nchw");
+}

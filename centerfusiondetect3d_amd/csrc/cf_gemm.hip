@@ -1,0 +1,391 @@
+// Implicit-GEMM convolution and DCNv2 on the gfx950 fp32 MFMA pipe (v_mfma_f32_32x32x2_f32).
+//
+// GEMM view  D[m][n] = sum_k A[m][k] * Wt[n][k]
+//   m : output pixel (b, ho, wo)          M = B*Ho*Wo
+//   n : output channel                     N_pad (multiple of 32)
+//   k : (tap, input channel) in host-defined slot order, K_pad multiple of 32
+// A is never materialised: each workgroup stages a BM x 32 A-chunk into LDS straight from the
+// NHWC activations (conv: plain taps; DCN: 4-corner bilinear gather, mask-modulated), and a
+// BN x 32 chunk of the pre-packed weights.  Four waves (256 threads) per workgroup; each wave owns
+// a (TM*32) x (TN*32) sub-tile as TM*TN 32x32 fp32 accumulators (16 VGPRs each).
+//
+// LDS rows are padded to 36 floats so the per-lane ds_read_b128 of 16 consecutive rows lands on 16
+// distinct 4-bank slots (conflict-free); all 64 lanes of a wave read row (lane&31), k-offset
+// 4*(lane>>5) - the two halves of the wave supply the two k-slots of each 32x32x2 MFMA.
+//
+// fp32 MFMA is exact fp32 (an fmaf chain) and runs at 64 FLOP/clk/SIMD, so one workgroup spends
+// 64 cycles per MFMA: global->LDS staging (one float4 per thread per 32 rows) hides completely
+// behind it once the next chunk is prefetched into registers during the current chunk's MFMAs.
+#include "cf_common.h"
+
+namespace {
+
+struct EpilogueArgs {
+  const float* bias;
+  const float* residual;
+  float* out;
+  float* out2;
+  int res_stride, out_stride, out_layout, act;
+  int M, N, HoWo;
+};
+
+struct ConvK {
+  const float* src[CF_MAX_SRC];
+  int src_c[CF_MAX_SRC];
+  const float* weight;
+  const cf_slot* slots;
+  int H, W, Ho, Wo, stride, K_pad, n_chunks, NT;
+  EpilogueArgs ep;
+};
+
+struct DcnK {
+  const float* x;
+  const float* om;
+  const float* weight;
+  int om_stride, H, W, C, K_pad, n_chunks, NT, chunks_per_tap;
+  EpilogueArgs ep;
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
+                                          int a_row0, int b_row0, int lane, f32x16 (&acc)[TM][TN]) {
+  const int li = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < CF_BK / 8; ++ks) {
+    f32x4 a[TM], b[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+      a[tm] = *reinterpret_cast<const f32x4*>(&As[(a_row0 + tm * 32 + li) * CF_LDS_STRIDE + ks * 8 + h * 4]);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+      b[tn] = *reinterpret_cast<const f32x4*>(&Bs[(b_row0 + tn * 32 + li) * CF_LDS_STRIDE + ks * 8 + h * 4]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][t], b[tn][t], acc[tm][tn], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == CF_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == CF_ACT_SIGMOID_CLAMP) return fminf(fmaxf(cf_sigmoid(v), 1e-4f), 1.0f - 1e-4f);
+  return v;
+}
+
+// C/D layout of the 32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const EpilogueArgs& ep, int m_base, int n_base, int lane,
+                                         f32x16 (&acc)[TM][TN]) {
+  const int li = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int n = n_base + tn * 32 + li;
+    const bool n_ok = n < ep.N;
+    const float bias = n_ok ? ep.bias[n] : 0.0f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int m4 = m_base + tm * 32 + 8 * g + 4 * h;  // 4 consecutive pixels m4..m4+3
+        if (ep.out_layout == CF_LAYOUT_NHWC) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int m = m4 + e;
+            if (n_ok && m < ep.M) {
+              float v = acc[tm][tn][g * 4 + e] + bias;
+              if (ep.residual) v += ep.residual[(size_t)m * ep.res_stride + n];
+              ep.out[(size_t)m * ep.out_stride + n] = apply_act(v, ep.act);
+            }
+          }
+        } else {  // NCHW: lanes differ in channel, the 4 accumulator rows are 4 consecutive pixels
+          if (n_ok && m4 < ep.M) {
+            const int b = m4 / ep.HoWo, pix = m4 - b * ep.HoWo;
+            const size_t o = ((size_t)b * ep.N + n) * ep.HoWo + pix;
+            f32x4 v, v2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float raw = acc[tm][tn][g * 4 + e] + bias;
+              v[e] = apply_act(raw, ep.act);
+              v2[e] = 0.0f;
+              if (ep.act == CF_ACT_RAW_AND_SIGDEPTH) v2[e] = 1.0f / (cf_sigmoid(raw) + 1e-6f) - 1.0f;
+            }
+            if (m4 + 3 < ep.M && pix + 3 < ep.HoWo && (o & 3) == 0) {
+              *reinterpret_cast<f32x4*>(&ep.out[o]) = v;
+              if (ep.act == CF_ACT_RAW_AND_SIGDEPTH) *reinterpret_cast<f32x4*>(&ep.out2[o]) = v2;
+            } else {
+              for (int e = 0; e < 4; ++e) {
+                const int m = m4 + e;
+                if (m < ep.M) {
+                  const int bb = m / ep.HoWo, pp = m - bb * ep.HoWo;
+                  const size_t oo = ((size_t)bb * ep.N + n) * ep.HoWo + pp;
+                  ep.out[oo] = v[e];
+                  if (ep.act == CF_ACT_RAW_AND_SIGDEPTH) ep.out2[oo] = v2[e];
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Convolution
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
+  constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr int RA = BM / 32, RB = BN / 32;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * CF_LDS_STRIDE];
+  float* As = smem;
+  float* Bs = smem + BM * CF_LDS_STRIDE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lid = cf_xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / p.NT, nt = lid - mt * p.NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tr = tid >> 3, ts = tid & 7;
+
+  // per-thread staging rows: pixel -> top-left input coordinate
+  int y0[RA], x0[RA], boff[RA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    const int m = m0 + tr + 32 * j;
+    if (m < p.ep.M) {
+      const int b = m / HoWo, rem = m - b * HoWo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      y0[j] = ho * p.stride;
+      x0[j] = wo * p.stride;
+      boff[j] = b * p.H * p.W;
+    } else {
+      y0[j] = -(1 << 28);
+      x0[j] = 0;
+      boff[j] = 0;
+    }
+  }
+
+  f32x4 ra[RA], rb[RB];
+  auto load_chunk = [&](int c) {
+    const cf_slot sl = p.slots[c * 8 + ts];
+    const int src = __builtin_amdgcn_readfirstlane(p.slots[c * 8].src);
+    const float* sp = src == 1 ? p.src[1] : src == 2 ? p.src[2] : src == 3 ? p.src[3] : p.src[0];
+    const int sc = src == 1 ? p.src_c[1] : src == 2 ? p.src_c[2] : src == 3 ? p.src_c[3] : p.src_c[0];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const int y = y0[j] + sl.dy, x = x0[j] + sl.dx;
+      const bool ok = (src >= 0) && (sl.c_off >= 0) && ((unsigned)y < (unsigned)p.H) &&
+                      ((unsigned)x < (unsigned)p.W);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(sp + (size_t)(boff[j] + y * p.W + x) * sc + sl.c_off);
+      ra[j] = v;
+    }
+    const float* wp = p.weight + (size_t)(n0 + tr) * p.K_pad + c * CF_BK + ts * 4;
+#pragma unroll
+    for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * j) * p.K_pad);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  load_chunk(0);
+  for (int c = 0; c < p.n_chunks; ++c) {
+    __syncthreads();  // previous chunk's LDS reads are done
+#pragma unroll
+    for (int j = 0; j < RA; ++j)
+      *reinterpret_cast<f32x4*>(&As[(tr + 32 * j) * CF_LDS_STRIDE + ts * 4]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+      *reinterpret_cast<f32x4*>(&Bs[(tr + 32 * j) * CF_LDS_STRIDE + ts * 4]) = rb[j];
+    __syncthreads();
+    if (c + 1 < p.n_chunks) load_chunk(c + 1);  // in flight while the MFMAs below run
+    mma_chunk<TM, TN>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+  }
+  epilogue<TM, TN>(p.ep, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// DCNv2 (3x3, stride 1, pad 1): bilinear gather fused into the A-chunk staging
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void dcn_igemm_kernel(DcnK p) {
+  constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr int RA = BM / 32, RB = BN / 32;
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * CF_LDS_STRIDE];
+  float* As = smem;
+  float* Bs = smem + BM * CF_LDS_STRIDE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lid = cf_xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = lid / p.NT, nt = lid - mt * p.NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tr = tid >> 3, ts = tid & 7;
+  const int HW = p.H * p.W;
+
+  int ho[RA], wo[RA], boff[RA], mrow[RA];
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    const int m = m0 + tr + 32 * j;
+    mrow[j] = m < p.ep.M ? m : -1;
+    const int mm = m < p.ep.M ? m : 0;
+    const int b = mm / HW, rem = mm - b * HW;
+    ho[j] = rem / p.W;
+    wo[j] = rem - ho[j] * p.W;
+    boff[j] = b * HW;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  for (int c = 0; c < p.n_chunks; ++c) {
+    const int tap = c / p.chunks_per_tap;
+    const int c0 = (c - tap * p.chunks_per_tap) * CF_BK + ts * 4;
+    const int ti = tap / 3, tj = tap - ti * 3;
+    f32x4 ra[RA], rb[RB];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (mrow[j] >= 0) {
+        const float* om = p.om + (size_t)mrow[j] * p.om_stride;
+        const float dy = om[2 * tap], dx = om[2 * tap + 1];
+        const float mk = cf_sigmoid(om[18 + tap]);
+        const float hf = (float)(ho[j] - 1 + ti) + dy;
+        const float wf = (float)(wo[j] - 1 + tj) + dx;
+        if (hf > -1.0f && hf < (float)p.H && wf > -1.0f && wf < (float)p.W) {
+          const float hfl = floorf(hf), wfl = floorf(wf);
+          const int hl = (int)hfl, wl = (int)wfl;
+          const float lh = hf - hfl, lw = wf - wfl, hh = 1.0f - lh, hw = 1.0f - lw;
+          const float* base = p.x + (size_t)boff[j] * p.C + c0;
+          const bool t_ok = hl >= 0, b_ok = hl + 1 <= p.H - 1, l_ok = wl >= 0, r_ok = wl + 1 <= p.W - 1;
+          f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
+          if (t_ok && l_ok) v1 = *reinterpret_cast<const f32x4*>(base + (size_t)(hl * p.W + wl) * p.C);
+          if (t_ok && r_ok) v2 = *reinterpret_cast<const f32x4*>(base + (size_t)(hl * p.W + wl + 1) * p.C);
+          if (b_ok && l_ok) v3 = *reinterpret_cast<const f32x4*>(base + (size_t)((hl + 1) * p.W + wl) * p.C);
+          if (b_ok && r_ok) v4 = *reinterpret_cast<const f32x4*>(base + (size_t)((hl + 1) * p.W + wl + 1) * p.C);
+          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+          v = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * mk;
+        }
+      }
+      ra[j] = v;
+    }
+    const float* wp = p.weight + (size_t)(n0 + tr) * p.K_pad + c * CF_BK + ts * 4;
+#pragma unroll
+    for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * j) * p.K_pad);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RA; ++j)
+      *reinterpret_cast<f32x4*>(&As[(tr + 32 * j) * CF_LDS_STRIDE + ts * 4]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+      *reinterpret_cast<f32x4*>(&Bs[(tr + 32 * j) * CF_LDS_STRIDE + ts * 4]) = rb[j];
+    __syncthreads();
+    mma_chunk<TM, TN>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+  }
+  epilogue<TM, TN>(p.ep, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, acc);
+}
+
+struct TileCfg {
+  int bm, bn;
+};
+
+// Tile choice: widest N tile that divides N_pad; drop to 64-row tiles when the grid would not
+// give every CU (256) at least two workgroups.
+TileCfg pick_tile(long M, int N_pad) {
+  TileCfg t;
+  t.bn = (N_pad % 128 == 0) ? 128 : (N_pad % 64 == 0) ? 64 : 32;
+  const long blocks128 = ((M + 127) / 128) * (N_pad / t.bn);
+  t.bm = blocks128 >= 512 ? 128 : 64;
+  return t;
+}
+
+}  // namespace
+
+#define LAUNCH_TILE(KERNEL, ARGS, BM_, BN_, WM_, WN_)                                   \
+  do {                                                                                  \
+    const int MT = (int)((M + BM_ - 1) / BM_), NT = N_pad / BN_;                        \
+    ARGS.NT = NT;                                                                       \
+    hipLaunchKernelGGL((KERNEL<BM_, BN_, WM_, WN_>), dim3(MT * NT), dim3(256), 0, st, ARGS); \
+  } while (0)
+
+#define DISPATCH_TILE(KERNEL, ARGS)                                        \
+  do {                                                                     \
+    const TileCfg t = pick_tile(M, N_pad);                                 \
+    if (t.bm == 128 && t.bn == 128) LAUNCH_TILE(KERNEL, ARGS, 128, 128, 2, 2); \
+    else if (t.bm == 128 && t.bn == 64) LAUNCH_TILE(KERNEL, ARGS, 128, 64, 2, 2); \
+    else if (t.bm == 128 && t.bn == 32) LAUNCH_TILE(KERNEL, ARGS, 128, 32, 4, 1); \
+    else if (t.bm == 64 && t.bn == 128) LAUNCH_TILE(KERNEL, ARGS, 64, 128, 1, 4); \
+    else if (t.bm == 64 && t.bn == 64) LAUNCH_TILE(KERNEL, ARGS, 64, 64, 2, 2);   \
+    else LAUNCH_TILE(KERNEL, ARGS, 128, 32, 4, 1);                         \
+  } while (0)
+
+extern "C" int cf_conv2d_fused(const cf_conv_args* a, void* stream) {
+  CF_REQUIRE(a != nullptr, "cf_conv2d_fused: null args");
+  CF_REQUIRE(a->n_src >= 1 && a->n_src <= CF_MAX_SRC, "cf_conv2d_fused: n_src=%d", a->n_src);
+  CF_REQUIRE(a->K_pad > 0 && a->K_pad % CF_BK == 0, "cf_conv2d_fused: K_pad=%d not a multiple of 32", a->K_pad);
+  CF_REQUIRE(a->N_pad >= a->N && a->N_pad % 32 == 0 && a->N > 0, "cf_conv2d_fused: N=%d N_pad=%d", a->N, a->N_pad);
+  CF_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Ho > 0 && a->Wo > 0 && a->stride > 0, "cf_conv2d_fused: bad geometry");
+  CF_REQUIRE(a->weight && a->slots && a->bias && a->out, "cf_conv2d_fused: null buffer");
+  CF_REQUIRE(a->act != CF_ACT_RAW_AND_SIGDEPTH || (a->out2 && a->out_layout == CF_LAYOUT_NCHW),
+             "cf_conv2d_fused: RAW_AND_SIGDEPTH needs out2 and NCHW");
+  CF_REQUIRE(a->out_layout == CF_LAYOUT_NCHW || a->out_stride >= a->N, "cf_conv2d_fused: out_stride < N");
+  for (int i = 0; i < a->n_src; ++i)
+    CF_REQUIRE(a->src[i] && a->src_c[i] > 0 && a->src_c[i] % 4 == 0, "cf_conv2d_fused: source %d invalid", i);
+  const long M = (long)a->B * a->Ho * a->Wo;
+  CF_REQUIRE((long)a->B * a->H * a->W * 4 < (1L << 31) && M < (1L << 31), "cf_conv2d_fused: tensor too large");
+  ConvK k{};
+  for (int i = 0; i < CF_MAX_SRC; ++i) {
+    k.src[i] = i < a->n_src ? a->src[i] : nullptr;
+    k.src_c[i] = i < a->n_src ? a->src_c[i] : 0;
+  }
+  k.weight = a->weight;
+  k.slots = a->slots;
+  k.H = a->H; k.W = a->W; k.Ho = a->Ho; k.Wo = a->Wo; k.stride = a->stride;
+  k.K_pad = a->K_pad;
+  k.n_chunks = a->K_pad / CF_BK;
+  k.ep = EpilogueArgs{a->bias, a->residual, a->out, a->out2, a->res_stride, a->out_stride,
+                      a->out_layout, a->act, (int)M, a->N, a->Ho * a->Wo};
+  const int N_pad = a->N_pad;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_TILE(conv_igemm_kernel, k);
+  return cf_check_launch("cf_conv2d_fused");
+}
+
+extern "C" int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream) {
+  CF_REQUIRE(a != nullptr, "cf_dcn_v2_fused: null args");
+  CF_REQUIRE(a->C > 0 && a->C % CF_BK == 0, "cf_dcn_v2_fused: C=%d not a multiple of 32", a->C);
+  CF_REQUIRE(a->N_pad >= a->N && a->N_pad % 32 == 0 && a->N > 0, "cf_dcn_v2_fused: N=%d N_pad=%d", a->N, a->N_pad);
+  CF_REQUIRE(a->om_stride >= 27, "cf_dcn_v2_fused: om_stride=%d < 27", a->om_stride);
+  CF_REQUIRE(a->x && a->offmask && a->weight && a->bias && a->out, "cf_dcn_v2_fused: null buffer");
+  CF_REQUIRE(a->out_stride >= a->N, "cf_dcn_v2_fused: out_stride < N");
+  const long M = (long)a->B * a->H * a->W;
+  CF_REQUIRE(M > 0 && M * a->C < (1L << 31) * 2, "cf_dcn_v2_fused: bad geometry");
+  DcnK k{};
+  k.x = a->x; k.om = a->offmask; k.weight = a->weight;
+  k.om_stride = a->om_stride; k.H = a->H; k.W = a->W; k.C = a->C;
+  k.K_pad = 9 * a->C;
+  k.n_chunks = k.K_pad / CF_BK;
+  k.chunks_per_tap = a->C / CF_BK;
+  k.ep = EpilogueArgs{a->bias, nullptr, a->out, nullptr, 0, a->out_stride, CF_LAYOUT_NHWC, a->act,
+                      (int)M, a->N, a->H * a->W};
+  const int N_pad = a->N_pad;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_TILE(dcn_igemm_kernel, k);
+  return cf_check_launch("cf_dcn_v2_fused");
+}

@@ -1,0 +1,567 @@
+// Index-path kernels of the CenterFusion forward: peak top-K (optionally behind the 3x3 equality
+// NMS), radar frustum association, detection gather and radar pillar expansion.
+//
+// These are integer / compare / scatter kernels bounded by HBM and LDS, not by the MFMA pipe; the
+// arithmetic that decides integer results (slice bounds, gates, rounding) is written operation for
+// operation like the reference's fp32 / fp64 expressions, and this file is compiled with
+// -ffp-contract=off so no multiply-add is fused behind our back.
+//
+// One workgroup per image/frame: the per-image working set (10x112x200 scores = 896 KB, 3x112x200
+// radar map = 269 KB) is L2-resident after the first pass, and every ordering decision (top-K
+// order, "last painted box wins", "farthest radar point wins") is resolved inside LDS.
+#include "cf_common.h"
+
+namespace {
+
+constexpr int TOPK_THREADS = 1024;
+constexpr int TOPK_CAP = 4096;  // candidate keys kept in LDS (32 KiB)
+
+__device__ __forceinline__ uint32_t f2u(float f) {  // order-preserving float -> uint
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float u2f(uint32_t u) {
+  return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// score of flat element i = (c, y, x) of one image; with NMS: heat * (maxpool3x3(heat) == heat)
+template <bool NMS>
+__device__ __forceinline__ float peak_value(const float* __restrict__ img, int i, int H, int W) {
+  const float v = img[i];
+  if (!NMS) return v;
+  const int HW = H * W;
+  const int c = i / HW, pix = i - c * HW;
+  const int y = pix / W, x = pix - y * W;
+  const float* pl = img + (size_t)c * HW;
+  float m = v;
+  const int y0 = y > 0 ? y - 1 : y, y1 = y < H - 1 ? y + 1 : y;
+  const int x0 = x > 0 ? x - 1 : x, x1 = x < W - 1 ? x + 1 : x;
+  for (int yy = y0; yy <= y1; ++yy)
+    for (int xx = x0; xx <= x1; ++xx) m = fmaxf(m, pl[yy * W + xx]);
+  return (m == v) ? v : v * 0.0f;
+}
+
+// Descending bitonic sort of P (power of two) 64-bit keys in LDS; whole workgroup participates.
+__device__ void bitonic_sort_desc(uint64_t* keys, int P) {
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint64_t a = keys[i], b = keys[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (a < b) : (a > b)) {
+            keys[i] = b;
+            keys[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Top-K of one image, ordered by (score desc, flat index asc) == (score desc, class asc, pixel asc).
+//  A. every thread takes the max of its strided share -> the K-th largest of the 1024 local maxima
+//     is a lower bound L of the K-th largest element (at least K elements are >= L);
+//  B. elements > L are collected into LDS; if fewer than K, the missing ones are the elements == L
+//     with the smallest indices, taken by an index-ordered block scan (this is the common case on
+//     real heat maps: the clamp plateau at 1e-4 ties everywhere);
+//  C. the <= 4096 candidates are bitonic-sorted on (score, ~index) keys.
+// If more than 4096 elements exceed L (adversarial input), the exact K-th value is found by a
+// 4 x 8-bit radix select and step B is repeated with it.
+template <bool NMS>
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ heat, int C, int H,
+                                                            int W, int K, float* __restrict__ scores,
+                                                            int32_t* __restrict__ inds,
+                                                            int32_t* __restrict__ classes) {
+  __shared__ uint64_t keys[TOPK_CAP];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t wave_cnt[TOPK_THREADS / 64];
+  __shared__ uint32_t s_gt, s_sel[3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HW = H * W, N = C * HW;
+  const float* img = heat + (size_t)blockIdx.x * N;
+
+  // ---- A: lower bound from local maxima
+  uint32_t lmax = 0;
+  for (int i = tid; i < N; i += TOPK_THREADS) lmax = max(lmax, f2u(peak_value<NMS>(img, i, H, W)));
+  keys[tid] = lmax;
+  __syncthreads();
+  bitonic_sort_desc(keys, TOPK_THREADS);
+  uint32_t L = (uint32_t)keys[K - 1];
+  __syncthreads();
+
+  // ---- B: collect everything strictly above the bound
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (tid == 0) s_gt = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += TOPK_THREADS) {
+      const uint32_t u = f2u(peak_value<NMS>(img, i, H, W));
+      if (u > L) {
+        const uint32_t pos = atomicAdd(&s_gt, 1u);
+        if (pos < TOPK_CAP) keys[pos] = ((uint64_t)u << 32) | (uint32_t)(~(uint32_t)i);
+      }
+    }
+    __syncthreads();
+    if (s_gt <= TOPK_CAP) break;
+    // exact K-th largest value by radix select (rare path)
+    uint32_t prefix = 0, mask = 0, need = K;
+    for (int pass = 3; pass >= 0; --pass) {
+      const int shift = pass * 8;
+      for (int i = tid; i < 256; i += TOPK_THREADS) hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < N; i += TOPK_THREADS) {
+        const uint32_t u = f2u(peak_value<NMS>(img, i, H, W));
+        if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t acc = 0;
+        int bin = 255;
+        for (; bin > 0; --bin) {
+          if (acc + hist[bin] >= need) break;
+          acc += hist[bin];
+        }
+        s_sel[0] = (uint32_t)bin;
+        s_sel[1] = need - acc;
+      }
+      __syncthreads();
+      prefix |= s_sel[0] << shift;
+      mask |= 255u << shift;
+      need = s_sel[1];
+      __syncthreads();
+    }
+    L = prefix;  // now fewer than K elements are strictly greater
+  }
+  const int g = (int)s_gt;
+  int total = g;
+  if (g < K) {
+    // index-ordered selection of the (K - g) smallest-index elements equal to L
+    const int r = K - g;
+    int found = 0;
+    for (int base = 0; base < N && found < r; base += TOPK_THREADS) {
+      const int i = base + tid;
+      const bool eq = (i < N) && (f2u(peak_value<NMS>(img, i, H, W)) == L);
+      const unsigned long long bal = __ballot(eq);
+      if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
+      __syncthreads();
+      int wave_off = 0, all = 0;
+      for (int w = 0; w < TOPK_THREADS / 64; ++w) {
+        const int cw = (int)wave_cnt[w];
+        if (w < wave) wave_off += cw;
+        all += cw;
+      }
+      if (eq) {
+        const int rank = found + wave_off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (rank < r) keys[g + rank] = ((uint64_t)L << 32) | (uint32_t)(~(uint32_t)i);
+      }
+      found += all;
+      __syncthreads();
+    }
+    total = K;
+  }
+  int P = 1;
+  while (P < total) P <<= 1;
+  for (int i = total + tid; i < P; i += TOPK_THREADS) keys[i] = 0;
+  __syncthreads();
+  bitonic_sort_desc(keys, P);
+  for (int j = tid; j < K; j += TOPK_THREADS) {
+    const uint64_t key = keys[j];
+    const uint32_t idx = ~(uint32_t)key;
+    const int c = (int)(idx / (uint32_t)HW);
+    scores[(size_t)blockIdx.x * K + j] = u2f((uint32_t)(key >> 32));
+    inds[(size_t)blockIdx.x * K + j] = (int32_t)(idx - (uint32_t)c * HW);
+    classes[(size_t)blockIdx.x * K + j] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Frustum association
+// ---------------------------------------------------------------------------------------------
+constexpr int FR_THREADS = 1024;
+constexpr int FR_MAXK = 256;
+
+__device__ __forceinline__ void py_slice(int start, int stop, int n, int& s, int& e) {
+  if (start < 0) {
+    start += n;
+    if (start < 0) start = 0;
+  } else if (start > n) {
+    start = n;
+  }
+  if (stop < 0) {
+    stop += n;
+    if (stop < 0) stop = 0;
+  } else if (stop > n) {
+    stop = n;
+  }
+  s = start;
+  e = stop;
+}
+
+struct FrBox {
+  int roi_y0, roi_y1, roi_x0, roi_x1;  // ROI of pc_dep searched for a radar hit
+  int p_y0, p_y1, p_x0, p_x1;          // rectangle painted on a hit
+  float lo, hi;                        // strict depth gate
+  float val[3];                        // painted values (depth/max_dist, vx, vz)
+  int found;
+};
+
+__global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
+    const int32_t* __restrict__ inds, int K, const float* __restrict__ depth, const float* __restrict__ wh,
+    const float* __restrict__ dim, const float* __restrict__ rot, const float* __restrict__ calib,
+    const float* __restrict__ pc_dep, int H, int W, float max_pc_dist, float* __restrict__ pc_hm,
+    float* __restrict__ pc_hm_nhwc4) {
+  __shared__ FrBox box[FR_MAXK];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HW = H * W;
+  const float* dep_b = depth + (size_t)b * HW;
+  const float* wh_b = wh + (size_t)b * 2 * HW;
+  const float* dim_b = dim + (size_t)b * 3 * HW;
+  const float* rot_b = rot + (size_t)b * 8 * HW;
+  const float* cal = calib + (size_t)b * 12;
+  const float* pc = pc_dep + (size_t)b * 3 * HW;
+
+  // ---- per-box geometry (utils/pointcloud.py:347-381, 397-437, 468-476)
+  if (tid < K) {
+    const int pix = inds[(size_t)b * K + tid];
+    const int yi = pix / W, xi = pix - yi * W;
+    const float xs = (float)xi + 0.5f, ys = (float)yi + 0.5f;
+    float w = wh_b[pix], h = wh_b[HW + pix];
+    w = w < 0.0f ? 0.0f : w;
+    h = h < 0.0f ? 0.0f : h;
+    const float b0 = xs - w / 2.0f, b1 = ys - h / 2.0f, b2 = xs + w / 2.0f, b3 = ys + h / 2.0f;
+    const float d = dep_b[pix];
+    // get_alpha
+    float r[8];
+    for (int i = 0; i < 8; ++i) r[i] = rot_b[(size_t)i * HW + pix];
+    const float idx = r[1] > r[5] ? 1.0f : 0.0f;
+    const float a1 = atan2f(r[2], r[3]) + (float)(-0.5 * M_PI);
+    const float a2 = atan2f(r[6], r[7]) + (float)(0.5 * M_PI);
+    const float alpha = a1 * idx + a2 * (1.0f - idx);
+    // getDistanceThresh: yaw, rotated box corners, max(z) - min(z)/2
+    const float cx = (b0 + b2) / 2.0f, cy = (b1 + b3) / 2.0f;
+    float yaw = alpha + atan2f(cx - cal[2], cal[0]);
+    const float PI_F = (float)M_PI, TWO_PI_F = (float)(2.0 * M_PI);
+    if (yaw > PI_F) yaw -= TWO_PI_F;
+    if (yaw < -PI_F) yaw += TWO_PI_F;
+    const float cs = cosf(yaw), sn = sinf(yaw);
+    const float dh = dim_b[pix], dw = dim_b[HW + pix], dl = dim_b[2 * HW + pix];
+    const float hx = 0.5f * dl, hz = 0.5f * dw;
+    const float sx[4] = {hx, hx, -hx, -hx}, sz[4] = {hz, -hz, -hz, hz};
+    float zmax = -INFINITY, zmin = INFINITY;
+    for (int q = 0; q < 8; ++q) {
+      const float yc = q < 4 ? 0.0f : -dh;
+      const float z = ((-sn) * sx[q & 3] + 0.0f * yc) + cs * sz[q & 3];
+      zmax = fmaxf(zmax, z);
+      zmin = fminf(zmin, z);
+    }
+    const float thr = zmax - zmin / 2.0f;
+    FrBox bx;
+    py_slice((int)floorf(b1), (int)ceilf(b3) + 1, H, bx.roi_y0, bx.roi_y1);
+    py_slice((int)floorf(b0), (int)ceilf(b2) + 1, W, bx.roi_x0, bx.roi_x1);
+    bx.hi = d + thr;
+    const float t = d - thr;
+    bx.lo = t > 0.0f ? t : 0.0f;
+    const float wi = 0.3f * (b2 - b0), hi_ = 0.3f * (b3 - b1);
+    const int w_min = (int)(cx - wi / 2.0f), w_max = (int)(cx + wi / 2.0f);
+    const int h_min = (int)(cy - hi_ / 2.0f), h_max = (int)(cy + hi_ / 2.0f);
+    py_slice(h_min, h_max + 1, H, bx.p_y0, bx.p_y1);
+    py_slice(w_min, w_max + 2, W, bx.p_x0, bx.p_x1);
+    bx.found = 0;
+    bx.val[0] = bx.val[1] = bx.val[2] = 0.0f;
+    box[tid] = bx;
+  }
+  __syncthreads();
+
+  // ---- nearest gated radar return inside each ROI: one wave per box, row-major first-minimum
+  for (int i = wave; i < K; i += FR_THREADS / 64) {
+    const FrBox bx = box[i];
+    const int rw = bx.roi_x1 - bx.roi_x0, rh = bx.roi_y1 - bx.roi_y0;
+    if (rw <= 0 || rh <= 0) continue;
+    const int n = rw * rh;
+    float best = INFINITY;
+    int best_pos = -1;
+    for (int base = 0; base < n; base += 64) {
+      const int q = base + lane;
+      float dv = INFINITY;
+      if (q < n) {
+        const int yy = bx.roi_y0 + q / rw, xx = bx.roi_x0 + q % rw;
+        const float v = pc[yy * W + xx];
+        if (v != 0.0f && v < bx.hi && v > bx.lo) dv = v;
+      }
+      float mn = dv;
+      for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
+      if (mn < best) {  // strict: an earlier chunk keeps ties
+        const unsigned long long bal = __ballot(dv == mn);
+        best = mn;
+        best_pos = base + (int)__ffsll((long long)bal) - 1;
+      }
+    }
+    if (lane == 0 && best_pos >= 0) {
+      const int yy = bx.roi_y0 + best_pos / rw, xx = bx.roi_x0 + best_pos % rw;
+      box[i].found = 1;
+      box[i].val[0] = best / max_pc_dist;
+      box[i].val[1] = pc[HW + yy * W + xx];
+      box[i].val[2] = pc[2 * HW + yy * W + xx];
+    }
+  }
+  __syncthreads();
+
+  // ---- paint: boxes are drawn in top-k order, so for every pixel the LAST covering hit wins
+  float* hm = pc_hm + (size_t)b * 3 * HW;
+  for (int p = tid; p < HW; p += FR_THREADS) {
+    const int y = p / W, x = p - y * W;
+    float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+    for (int i = K - 1; i >= 0; --i) {
+      const FrBox& bx = box[i];
+      if (bx.found && y >= bx.p_y0 && y < bx.p_y1 && x >= bx.p_x0 && x < bx.p_x1) {
+        v0 = bx.val[0];
+        v1 = bx.val[1];
+        v2 = bx.val[2];
+        break;
+      }
+    }
+    hm[p] = v0;
+    hm[HW + p] = v1;
+    hm[2 * HW + p] = v2;
+    if (pc_hm_nhwc4) {
+      const f32x4 o = {v0, v1, v2, 0.0f};
+      reinterpret_cast<f32x4*>(pc_hm_nhwc4)[(size_t)b * HW + p] = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Detection gather (model/decode.py:40-41, 60-64, 132-172)
+// ---------------------------------------------------------------------------------------------
+__global__ void decode_gather_kernel(cf_decode_args a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.B * a.K) return;
+  const int b = t / a.K;
+  const int HW = a.H * a.W;
+  const int pix = a.inds[t];
+  const int yi = pix / a.W, xi = pix - yi * a.W;
+  float* o = a.det + (size_t)t * 33;
+  const float xn = (float)xi / (float)a.W, yn = (float)yi / (float)a.H;
+  o[0] = a.scores[t];
+  o[1] = (float)a.classes[t];
+  o[2] = xn;
+  o[3] = yn;
+  const float xf = xn * (float)a.out_w, yf = yn * (float)a.out_h;
+  float xc, yc;
+  if (a.reg) {
+    xc = xf + a.reg[((size_t)b * 2 + 0) * HW + pix];
+    yc = yf + a.reg[((size_t)b * 2 + 1) * HW + pix];
+  } else {
+    xc = xf + 0.5f;
+    yc = yf + 0.5f;
+  }
+  const float sx = a.norm2d ? (float)a.out_w : 1.0f, sy = a.norm2d ? (float)a.out_h : 1.0f;
+  if (a.wh) {
+    float w = a.wh[((size_t)b * 2 + 0) * HW + pix], h = a.wh[((size_t)b * 2 + 1) * HW + pix];
+    w = (w < 0.0f ? 0.0f : w) * sx;
+    h = (h < 0.0f ? 0.0f : h) * sy;
+    o[4] = xc - w / 2.0f;
+    o[5] = yc - h / 2.0f;
+    o[6] = xc + w / 2.0f;
+    o[7] = yc + h / 2.0f;
+  } else {
+    o[4] = o[5] = o[6] = o[7] = 0.0f;
+  }
+  auto gather = [&](const float* m, int nc, int off, float s0, float s1) {
+    for (int c = 0; c < nc; ++c) {
+      float v = m ? m[((size_t)b * nc + c) * HW + pix] : 0.0f;
+      if (m) v *= (c == 0 ? s0 : (c == 1 ? s1 : 1.0f));
+      o[off + c] = v;
+    }
+  };
+  gather(a.rot, 8, 8, 1.0f, 1.0f);
+  gather(a.dim, 3, 16, 1.0f, 1.0f);
+  gather(a.amodal, 2, 19, sx, sy);
+  gather(a.att, 8, 21, 1.0f, 1.0f);
+  gather(a.vel, 3, 29, 1.0f, 1.0f);
+  gather(a.depth, 1, 32, 1.0f, 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pillar expansion (dataset/generic_dataset.py:738-942, datasets/nuscenes.py:221-263), fp64
+// ---------------------------------------------------------------------------------------------
+constexpr int PL_THREADS = 256;
+constexpr int PL_MAXN = 1024;
+
+struct PlBox {
+  int y0, y1, x0, x1;
+  float d, vx, vz;
+};
+
+// One workgroup per frame.  (1) per-point fp64 geometry -> integer box; (2) LDS rank map: every kept
+// point atomicMax-es its depth rank over its rectangle, a wave per point (points are depth-ascending,
+// painting order = rank order, so the surviving value of a pixel is that of its highest rank);
+// (3) resolve ranks to (depth, vx, vz).  The rank map is processed in row bands that fit LDS.
+__global__ __launch_bounds__(PL_THREADS) void pillar_kernel(
+    const double* __restrict__ pc_2d, const double* __restrict__ pc_3d, const int32_t* __restrict__ counts,
+    int max_n, int n_rows, const double* __restrict__ calib, const double* __restrict__ trans, int H, int W,
+    double ph, double pw, double pl, float* __restrict__ pc_dep, uint8_t* __restrict__ keep_mask,
+    double* __restrict__ xy_out, int band_rows) {
+  extern __shared__ __attribute__((aligned(16))) int rank_map[];  // band_rows * W
+  __shared__ PlBox box[PL_MAXN];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = counts[b];
+  const double* p2 = pc_2d + (size_t)b * 3 * max_n;
+  const double* p3 = pc_3d + (size_t)b * n_rows * max_n;
+  const double* cal = calib + (size_t)b * 12;
+  const double* m = trans + (size_t)b * 6;
+
+  for (int i = tid; i < max_n; i += PL_THREADS) {
+    PlBox bx;
+    bx.y0 = bx.y1 = bx.x0 = bx.x1 = 0;
+    bx.d = bx.vx = bx.vz = 0.0f;
+    bool keep = false;
+    double tx = 0.0, ty = 0.0;
+    if (i < n) {
+      const double u = p2[i], v = p2[max_n + i];
+      tx = m[0] * u + m[1] * v + m[2];
+      ty = m[3] * u + m[4] * v + m[5];
+      keep = (tx < (double)W) && (ty < (double)H) && (0.0 < tx) && (0.0 < ty);
+      if (keep) {
+        // 8 corners of the (h,w,l) pillar standing on the point, yaw 0; corner offsets are float32
+        // in the reference (numpy float32 arrays), the sum with the fp64 location is fp64.
+        const double X = p3[i], Y = p3[max_n + i], Z = p3[2 * (size_t)max_n + i];
+        const double ox = (double)(float)(0.5 * pl), oz = (double)(float)(0.5 * pw);
+        const double oy = (double)(float)(-ph);
+        double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        for (int q = 0; q < 8; ++q) {
+          const double cxq = X + ((q & 3) < 2 ? ox : -ox);
+          const double cyq = Y + (q < 4 ? 0.0 : oy);
+          const double czq = Z + (((q & 3) == 0 || (q & 3) == 3) ? oz : -oz);
+          const double pu = ((cal[0] * cxq + cal[1] * cyq) + cal[2] * czq) + cal[3];
+          const double pv = ((cal[4] * cxq + cal[5] * cyq) + cal[6] * czq) + cal[7];
+          const double pz = ((cal[8] * cxq + cal[9] * cyq) + cal[10] * czq) + cal[11];
+          const double uu = pu / pz, vv = pv / pz;
+          const double ou = m[0] * uu + m[1] * vv + m[2];
+          const double ov = m[3] * uu + m[4] * vv + m[5];
+          xmin = fmin(xmin, ou); xmax = fmax(xmax, ou);
+          ymin = fmin(ymin, ov); ymax = fmax(ymax, ov);
+        }
+        const double bw = xmax - xmin, bh = ymax - ymin;
+        const double y1 = fmax(ty - bh, 0.0), y2 = ty;
+        const double x1 = fmax(tx - bw / 2, 0.0), x2 = fmin(tx + bw / 2, (double)W);
+        // np.round == round-half-to-even == rint; then numpy slicing clips to the map
+        int iy0 = (int)rint(y1), iy1 = (int)rint(y2), ix0 = (int)rint(x1), ix1 = (int)rint(x2);
+        py_slice(iy0, iy1, H, bx.y0, bx.y1);
+        py_slice(ix0, ix1, W, bx.x0, bx.x1);
+        bx.d = (float)p2[2 * (size_t)max_n + i];
+        bx.vx = (float)p3[8 * (size_t)max_n + i];
+        bx.vz = (float)p3[9 * (size_t)max_n + i];
+      }
+    }
+    if (!keep) bx.y1 = bx.y0 = 0;
+    if (i < PL_MAXN) box[i] = bx;
+    if (keep_mask) keep_mask[(size_t)b * max_n + i] = keep ? 1 : 0;
+    if (xy_out) {
+      xy_out[((size_t)b * 2 + 0) * max_n + i] = tx;
+      xy_out[((size_t)b * 2 + 1) * max_n + i] = ty;
+    }
+  }
+  __syncthreads();
+
+  float* out = pc_dep + (size_t)b * 3 * H * W;
+  const int HW = H * W;
+  for (int r0 = 0; r0 < H; r0 += band_rows) {
+    const int r1 = min(r0 + band_rows, H);
+    const int cells = (r1 - r0) * W;
+    for (int i = tid; i < cells; i += PL_THREADS) rank_map[i] = -1;
+    __syncthreads();
+    for (int i = wave; i < n; i += PL_THREADS / 64) {
+      const PlBox bx = box[i];
+      const int ya = max(bx.y0, r0), yb = min(bx.y1, r1);
+      const int rw = bx.x1 - bx.x0;
+      if (yb <= ya || rw <= 0) continue;
+      const int cnt = (yb - ya) * rw;
+      for (int q = lane; q < cnt; q += 64) {
+        const int yy = ya + q / rw, xx = bx.x0 + q % rw;
+        atomicMax(&rank_map[(yy - r0) * W + xx], i);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < cells; i += PL_THREADS) {
+      const int rk = rank_map[i];
+      float d = 0.0f, vx = 0.0f, vz = 0.0f;
+      if (rk >= 0) {
+        d = box[rk].d;
+        vx = box[rk].vx;
+        vz = box[rk].vz;
+      }
+      const int p = r0 * W + i;
+      out[p] = d;
+      out[HW + p] = vx;
+      out[2 * HW + p] = vz;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" size_t cf_topk_workspace_bytes(int B) {
+  (void)B;
+  return 0;  // the selection runs entirely in LDS
+}
+
+extern "C" int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
+                             int32_t* inds, int32_t* classes, void* workspace, void* stream) {
+  (void)workspace;
+  CF_REQUIRE(heat && scores && inds && classes, "cf_topk_peaks: null buffer");
+  CF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cf_topk_peaks: bad geometry");
+  CF_REQUIRE(K >= 1 && K <= TOPK_THREADS, "cf_topk_peaks: K=%d outside [1,%d]", K, TOPK_THREADS);
+  CF_REQUIRE((long)C * H * W >= K, "cf_topk_peaks: fewer than K elements per image");
+  CF_REQUIRE((long)C * H * W < (1L << 31), "cf_topk_peaks: image too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (nms)
+    hipLaunchKernelGGL(topk_kernel<true>, dim3(B), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, scores, inds, classes);
+  else
+    hipLaunchKernelGGL(topk_kernel<false>, dim3(B), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, scores, inds, classes);
+  return cf_check_launch("cf_topk_peaks");
+}
+
+extern "C" int cf_frustum_assoc(const int32_t* inds, int K, const float* depth, const float* wh,
+                                const float* dim, const float* rot, const float* calib, const float* pc_dep,
+                                int B, int H, int W, float max_pc_dist, float* pc_hm, float* pc_hm_nhwc4,
+                                void* stream) {
+  CF_REQUIRE(inds && depth && wh && dim && rot && calib && pc_dep && pc_hm, "cf_frustum_assoc: null buffer");
+  CF_REQUIRE(K >= 1 && K <= FR_MAXK, "cf_frustum_assoc: K=%d outside [1,%d]", K, FR_MAXK);
+  CF_REQUIRE(B > 0 && H > 0 && W > 0, "cf_frustum_assoc: bad geometry");
+  hipLaunchKernelGGL(frustum_kernel, dim3(B), dim3(FR_THREADS), 0, (hipStream_t)stream, inds, K, depth, wh, dim,
+                     rot, calib, pc_dep, H, W, max_pc_dist, pc_hm, pc_hm_nhwc4);
+  return cf_check_launch("cf_frustum_assoc");
+}
+
+extern "C" int cf_decode_gather(const cf_decode_args* a, void* stream) {
+  CF_REQUIRE(a && a->scores && a->inds && a->classes && a->det, "cf_decode_gather: null buffer");
+  CF_REQUIRE(a->B > 0 && a->K > 0 && a->H > 0 && a->W > 0, "cf_decode_gather: bad geometry");
+  const int n = a->B * a->K;
+  hipLaunchKernelGGL(decode_gather_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, *a);
+  return cf_check_launch("cf_decode_gather");
+}
+
+extern "C" int cf_pillar_expand(const double* pc_2d, const double* pc_3d, const int32_t* counts, int B,
+                                int max_n, int n_rows, const double* calib, const double* trans, int H, int W,
+                                double pillar_h, double pillar_w, double pillar_l, float* pc_dep,
+                                uint8_t* keep_mask, double* xy_out, void* stream) {
+  CF_REQUIRE(pc_2d && pc_3d && counts && calib && trans && pc_dep, "cf_pillar_expand: null buffer");
+  CF_REQUIRE(B > 0 && H > 0 && W > 0, "cf_pillar_expand: bad geometry");
+  CF_REQUIRE(max_n >= 1 && max_n <= PL_MAXN, "cf_pillar_expand: max_n=%d outside [1,%d]", max_n, PL_MAXN);
+  CF_REQUIRE(n_rows >= 10, "cf_pillar_expand: pc_3d needs >= 10 rows (8 = vx, 9 = vz)");
+  int band_rows = H;
+  const int max_cells = (96 * 1024) / 4;  // 96 KiB of rank map per workgroup
+  if ((long)band_rows * W > max_cells) band_rows = max_cells / W;
+  CF_REQUIRE(band_rows >= 1, "cf_pillar_expand: W=%d too wide", W);
+  const size_t lds = (size_t)band_rows * W * sizeof(int);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pillar_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(pillar_kernel, dim3(B), dim3(PL_THREADS), lds, (hipStream_t)stream, pc_2d, pc_3d, counts,
+                     max_n, n_rows, calib, trans, H, W, pillar_h, pillar_w, pillar_l, pc_dep, keep_mask, xy_out,
+                     band_rows);
+  return cf_check_launch("cf_pillar_expand");
+}

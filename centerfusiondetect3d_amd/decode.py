@@ -1,0 +1,65 @@
+"""Drop-in for the reference's model/decode.py:10-174 (`fusionDecode`) on the HIP path.
+
+NMS + top-k run in one kernel over the NCHW heat map (cf_topk_peaks with nms=1) and the ten
+per-head gathers + box arithmetic in a second one (cf_decode_gather) that reads the K peak pixels
+straight from the NCHW maps - the reference's ten full-map permute().contiguous() copies
+(model/utils.py:69-71) do not exist here.  Order among equal scores: (class asc, pixel asc).
+"""
+import torch
+
+from . import ops
+
+# column layout of the (B,K,33) detection tensor (== SURVEY.md §8(e) all-gather payload)
+DET_FIELDS = [("scores", 1), ("classIds", 1), ("centers", 2), ("bboxes", 4), ("rotation", 8),
+              ("dimension", 3), ("amodal_offset", 2), ("nuscenes_att", 8), ("velocity", 3),
+              ("depth", 1)]
+DET_WIDTH = sum(n for _, n in DET_FIELDS)
+
+
+def decode_packed(outputs, outputSize=(112, 200), K=100, norm2d=False):
+    """-> (det (B,K,33) f32, present-field names).  Same side effect on `outputs` as the reference:
+    `rotation2` is renamed to `rotation` in the caller's dict (decode.py:120-121)."""
+    assert isinstance(outputs, list), "output must be a list of dictionaries"
+    if len(outputs) != 1:
+        raise NotImplementedError("the DLA-34 model yields one output layer; multi-layer decode is not on the path")
+    out = outputs[0]
+    if "heatmap" not in out:
+        return None, []
+    if "uncertainty" in out:
+        raise NotImplementedError("uncertainty head (TRAIN.UNCERTAINTY_LOSS) is outside the hot path")
+    heat = out["heatmap"]
+    _, _, H, W = heat.shape
+    scores, inds, classes = ops.topk_peaks(heat, K, nms=True)
+    depth = out.get("depth2", out.get("depth"))
+    if "rotation2" in out:
+        out["rotation"] = out.pop("rotation2")
+    maps = {"reg": out.get("reg"), "wh": out.get("widthHeight"), "depth": depth,
+            "rot": out.get("rotation"), "dim": out.get("dimension"),
+            "amodal": out.get("amodal_offset"), "att": out.get("nuscenes_att"),
+            "vel": out.get("velocity")}
+    det = ops.decode_gather(scores, inds, classes, maps, H, W, outputSize, norm2d)
+    present = ["scores", "classIds", "centers"]
+    for name, key in (("bboxes", "wh"), ("rotation", "rot"), ("dimension", "dim"),
+                      ("amodal_offset", "amodal"), ("nuscenes_att", "att"), ("velocity", "vel"),
+                      ("depth", "depth")):
+        if maps[key] is not None:
+            present.append(name)
+    return det, present
+
+
+def unpack_detections(det, present=None):
+    """(B,K,33) -> dict of tensors shaped like the reference's return value."""
+    ret, col = {}, 0
+    for name, n in DET_FIELDS:
+        if present is None or name in present:
+            v = det[..., col:col + n]
+            ret[name] = v[..., 0] if name in ("scores", "classIds") else v
+        col += n
+    return ret
+
+
+def fusionDecode(outputs, outputSize=(112, 200), K=100, norm2d=False):
+    det, present = decode_packed(outputs, outputSize, K, norm2d)
+    if det is None:
+        return {}
+    return unpack_detections(det, present)

@@ -1,0 +1,209 @@
+"""Operator-level host wrappers over the C ABI (include/cf_hip.h).
+
+Each function mirrors one operator the reference dispatches on the hot path (see the header for
+the file:line each replaces).  Tensors are torch CUDA(=HIP) tensors used purely as device memory;
+activations are NHWC fp32 (a (B,H,W,C) contiguous tensor).  Nothing here falls back to torch ops.
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, ACT_RAW_AND_SIGDEPTH, LAYOUT_NHWC,
+                   LAYOUT_NCHW)
+from .packing import PackedConv, PackedDcn
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.CfHipError("libcfhip operators need device tensors (no CPU path)")
+
+
+def conv_args(pc: PackedConv, srcs: Sequence[torch.Tensor], src_strides: Sequence[int], B, H, W,
+              out: torch.Tensor, out_stride: int, act=ACT_NONE, residual=None, res_stride=0,
+              layout=LAYOUT_NHWC, out2=None, out_offset=0) -> _lib.ConvArgs:
+    """Build (and return for reuse) the argument block of one fused convolution."""
+    a = _lib.ConvArgs()
+    for i, (s, c) in enumerate(zip(srcs, src_strides)):
+        a.src[i] = s.data_ptr()
+        a.src_c[i] = c
+    a.n_src = len(srcs)
+    a.B, a.H, a.W = B, H, W
+    a.Ho = (H + 2 * pc.pad - pc.kh) // pc.stride + 1
+    a.Wo = (W + 2 * pc.pad - pc.kh) // pc.stride + 1
+    a.stride = pc.stride
+    a.weight, a.slots, a.bias = pc.weight.data_ptr(), pc.slots.data_ptr(), pc.bias.data_ptr()
+    a.K_pad, a.N, a.N_pad = pc.k_pad, pc.n, pc.n_pad
+    a.residual = _lib.ptr(residual)
+    a.res_stride = res_stride
+    a.out = out.data_ptr() + 4 * out_offset
+    a.out2 = _lib.ptr(out2)
+    a.out_stride, a.out_layout, a.act = out_stride, layout, act
+    return a
+
+
+def run_conv(a: _lib.ConvArgs):
+    _lib.check(_lib.load().cf_conv2d_fused(C.byref(a), _lib.stream_ptr()), "cf_conv2d_fused")
+
+
+def conv2d_fused(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, residual=None, layout=LAYOUT_NHWC,
+                 out=None, out2=None):
+    """Convenience form: allocates the output.  srcs: NHWC tensors (B,H,W,Ci)."""
+    _need_cuda(*srcs, residual)
+    Ho = (H + 2 * pc.pad - pc.kh) // pc.stride + 1
+    Wo = (W + 2 * pc.pad - pc.kh) // pc.stride + 1
+    dev = srcs[0].device
+    if out is None:
+        shape = (B, Ho, Wo, pc.n) if layout == LAYOUT_NHWC else (B, pc.n, Ho, Wo)
+        out = torch.empty(shape, device=dev, dtype=torch.float32)
+    if act == ACT_RAW_AND_SIGDEPTH and out2 is None:
+        out2 = torch.empty_like(out)
+    a = conv_args(pc, srcs, [s.shape[-1] for s in srcs], B, H, W, out, pc.n, act, residual,
+                  residual.shape[-1] if residual is not None else 0, layout, out2)
+    run_conv(a)
+    return (out, out2) if act == ACT_RAW_AND_SIGDEPTH else out
+
+
+def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act=ACT_RELU):
+    a = _lib.DcnArgs()
+    a.x, a.offmask, a.om_stride = x.data_ptr(), offmask.data_ptr(), om_stride
+    a.B, a.H, a.W, a.C = B, H, W, pd.c
+    a.weight, a.bias, a.N, a.N_pad = pd.weight.data_ptr(), pd.bias.data_ptr(), pd.n, pd.n_pad
+    a.out, a.out_stride, a.act = out.data_ptr(), out_stride, act
+    return a
+
+
+def run_dcn(a: _lib.DcnArgs):
+    _lib.check(_lib.load().cf_dcn_v2_fused(C.byref(a), _lib.stream_ptr()), "cf_dcn_v2_fused")
+
+
+def dcn_v2_fused(pd: PackedDcn, x, offmask, act=ACT_RELU):
+    """x (B,H,W,C) NHWC, offmask (B,H,W,S>=27) NHWC raw conv_offset_mask output."""
+    _need_cuda(x, offmask)
+    B, H, W, _ = x.shape
+    out = torch.empty((B, H, W, pd.n), device=x.device, dtype=torch.float32)
+    run_dcn(dcn_args(pd, x, offmask, offmask.shape[-1], B, H, W, out, pd.n, act))
+    return out
+
+
+def upsample_dw(x, weight_kkc, f, skip=None, out=None):
+    _need_cuda(x, weight_kkc, skip)
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((B, H * f, W * f, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().cf_upsample_dw(x.data_ptr(), weight_kkc.data_ptr(), _lib.ptr(skip),
+                                          out.data_ptr(), B, H, W, Cc, f, _lib.stream_ptr()),
+               "cf_upsample_dw")
+    return out
+
+
+def maxpool2x2(x, out=None):
+    _need_cuda(x)
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((B, H // 2, W // 2, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().cf_maxpool2x2(x.data_ptr(), out.data_ptr(), B, H, W, Cc,
+                                         _lib.stream_ptr()), "cf_maxpool2x2")
+    return out
+
+
+def nchw_to_nhwc4(x, out=None):
+    _need_cuda(x)
+    B, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, 4), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().cf_nchw_to_nhwc4(x.data_ptr(), out.data_ptr(), B, Cc, H, W,
+                                            _lib.stream_ptr()), "cf_nchw_to_nhwc4")
+    return out
+
+
+def nhwc_to_nchw(x, channels=None, out=None):
+    _need_cuda(x)
+    B, H, W, S = x.shape
+    Cc = channels or S
+    if out is None:
+        out = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().cf_nhwc_to_nchw(x.data_ptr(), out.data_ptr(), B, H, W, Cc, S,
+                                           _lib.stream_ptr()), "cf_nhwc_to_nchw")
+    return out
+
+
+def topk_peaks(heat, K=100, nms=False):
+    """(B,C,H,W) NCHW scores -> scores (B,K) f32, inds (B,K) i32, classes (B,K) i32."""
+    _need_cuda(heat)
+    if not heat.is_contiguous():
+        heat = heat.contiguous()
+    B, Cc, H, W = heat.shape
+    dev = heat.device
+    scores = torch.empty((B, K), device=dev, dtype=torch.float32)
+    inds = torch.empty((B, K), device=dev, dtype=torch.int32)
+    classes = torch.empty((B, K), device=dev, dtype=torch.int32)
+    _lib.check(_lib.load().cf_topk_peaks(heat.data_ptr(), B, Cc, H, W, K, int(bool(nms)),
+                                         scores.data_ptr(), inds.data_ptr(), classes.data_ptr(),
+                                         None, _lib.stream_ptr()), "cf_topk_peaks")
+    return scores, inds, classes
+
+
+def frustum_assoc(inds, depth, wh, dim, rot, calib, pc_dep, max_pc_dist=60.0, want_nhwc4=False,
+                  pc_hm=None, pc_hm_nhwc4=None):
+    _need_cuda(inds, depth, wh, dim, rot, calib, pc_dep)
+    B, _, H, W = pc_dep.shape
+    K = inds.shape[1]
+    dev = pc_dep.device
+    if pc_hm is None:
+        pc_hm = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
+    if want_nhwc4 and pc_hm_nhwc4 is None:
+        pc_hm_nhwc4 = torch.empty((B, H, W, 4), device=dev, dtype=torch.float32)
+    ts = [t if t.is_contiguous() else t.contiguous() for t in (depth, wh, dim, rot, calib, pc_dep)]
+    _lib.check(_lib.load().cf_frustum_assoc(inds.data_ptr(), K, *(t.data_ptr() for t in ts), B, H,
+                                            W, float(max_pc_dist), pc_hm.data_ptr(),
+                                            _lib.ptr(pc_hm_nhwc4), _lib.stream_ptr()),
+               "cf_frustum_assoc")
+    return (pc_hm, pc_hm_nhwc4) if want_nhwc4 else pc_hm
+
+
+def decode_gather(scores, inds, classes, maps: dict, H, W, out_hw, norm2d=False):
+    """maps: optional NCHW tensors under reg/wh/depth/rot/dim/amodal/att/vel -> det (B,K,33)."""
+    _need_cuda(scores, inds, classes)
+    B, K = scores.shape
+    det = torch.empty((B, K, 33), device=scores.device, dtype=torch.float32)
+    a = _lib.DecodeArgs()
+    a.scores, a.inds, a.classes = scores.data_ptr(), inds.data_ptr(), classes.data_ptr()
+    keep = []
+    for name in ("reg", "wh", "depth", "rot", "dim", "amodal", "att", "vel"):
+        t = maps.get(name)
+        if t is not None and not t.is_contiguous():
+            t = t.contiguous()
+        keep.append(t)
+        setattr(a, name, _lib.ptr(t))
+    a.B, a.K, a.H, a.W = B, K, H, W
+    a.out_h, a.out_w, a.norm2d = int(out_hw[0]), int(out_hw[1]), int(bool(norm2d))
+    a.det = det.data_ptr()
+    _lib.check(_lib.load().cf_decode_gather(C.byref(a), _lib.stream_ptr()), "cf_decode_gather")
+    return det
+
+
+def pillar_expand(pc_2d, pc_3d, counts, calib, trans, out_hw, pillar_dims=(1.5, 0.2, 0.2),
+                  want_aux=False):
+    """pc_2d (B,3,Nmax) f64, pc_3d (B,R,Nmax) f64, counts (B) i32, calib (B,3,4) f64,
+    trans (B,2,3) f64  ->  pc_dep (B,3,H,W) f32 [, keep (B,Nmax) u8, xy (B,2,Nmax) f64]."""
+    _need_cuda(pc_2d, pc_3d, counts, calib, trans)
+    B, _, max_n = pc_2d.shape
+    H, W = out_hw
+    dev = pc_2d.device
+    pc_dep = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
+    keep = torch.empty((B, max_n), device=dev, dtype=torch.uint8) if want_aux else None
+    xy = torch.empty((B, 2, max_n), device=dev, dtype=torch.float64) if want_aux else None
+    for t, dt in ((pc_2d, torch.float64), (pc_3d, torch.float64), (counts, torch.int32),
+                  (calib, torch.float64), (trans, torch.float64)):
+        if t.dtype != dt or not t.is_contiguous():
+            raise _lib.CfHipError("cf_pillar_expand: wrong dtype / non-contiguous input")
+    h, w, l = pillar_dims
+    _lib.check(_lib.load().cf_pillar_expand(pc_2d.data_ptr(), pc_3d.data_ptr(), counts.data_ptr(),
+                                            B, max_n, pc_3d.shape[1], calib.data_ptr(),
+                                            trans.data_ptr(), H, W, float(h), float(w), float(l),
+                                            pc_dep.data_ptr(), _lib.ptr(keep), _lib.ptr(xy),
+                                            _lib.stream_ptr()), "cf_pillar_expand")
+    return (pc_dep, keep, xy) if want_aux else pc_dep

@@ -1,0 +1,122 @@
+"""One-time weight preparation for the HIP kernels (host side, runs at model load).
+
+  * eval-mode BatchNorm is folded into the producing conv:  w' = w * g/sqrt(v+eps),
+    b' = (b - mean) * g/sqrt(v+eps) + beta   (reference: dla.py:29,36-39,151-159 run BN as a
+    separate op; SURVEY.md Appendix B.12 for the DeformConv bias case);
+  * weights are re-laid-out as the K-contiguous [N_pad][K_pad] matrix the implicit GEMM reads, in
+    "slot" order: one slot = 4 consecutive input channels of one source tensor at one filter tap
+    (include/cf_hip.h: cf_slot).  A Root's channel concat (dla.py:35) or the feat||pc_hm concat of
+    the secondary heads (fusionModules.py:33) becomes several sources - nothing is concatenated
+    in memory.
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+BN_EPS = 1e-5
+BK = 32
+
+
+def fold_bn(weight, bias, bn):
+    """bn = (gamma, beta, mean, var) or None -> (weight', bias') float32 on CPU."""
+    w = weight.detach().float().cpu()
+    co = w.shape[0]
+    b = torch.zeros(co) if bias is None else bias.detach().float().cpu()
+    if bn is None:
+        return w, b
+    g, beta, mean, var = (t.detach().float().cpu() for t in bn)
+    scale = g / torch.sqrt(var + BN_EPS)
+    return w * scale.view(-1, *([1] * (w.dim() - 1))), (b - mean) * scale + beta
+
+
+@dataclass
+class Source:
+    channels: int      # real channels this source contributes to the conv's Cin
+    stride: int        # floats per pixel of the NHWC tensor holding it
+    c_base: int = 0    # first channel inside that tensor
+
+
+@dataclass
+class PackedConv:
+    weight: torch.Tensor          # [N_pad, K_pad] f32
+    bias: torch.Tensor            # [N_pad] f32
+    slots: torch.Tensor           # [K_pad/4, 4] int32 (src, dy, dx, c_off)
+    n: int
+    n_pad: int
+    k_pad: int
+    kh: int
+    stride: int
+    pad: int
+
+    def to(self, device):
+        self.weight = self.weight.to(device).contiguous()
+        self.bias = self.bias.to(device).contiguous()
+        self.slots = self.slots.to(device).contiguous()
+        return self
+
+
+def pack_conv(weight, bias, sources: Sequence[Source], stride=1, pad=None, dilation=1,
+              n_pad: Optional[int] = None) -> PackedConv:
+    """weight (Cout, sum(src.channels), kh, kw), BN already folded."""
+    co, ci, kh, kw = weight.shape
+    assert ci == sum(s.channels for s in sources), (ci, [s.channels for s in sources])
+    pad = (kh - 1) // 2 * dilation if pad is None else pad
+    n_pad = n_pad or ((co + 31) // 32) * 32
+    slots: List[List[int]] = []
+    cols = []      # per slot: (cin index of its first channel or -1, number of real channels)
+    c_lo = 0
+    for si, s in enumerate(sources):
+        per_tap = (s.channels + 3) // 4
+        n_slots = 0
+        for r in range(kh):
+            for q in range(kw):
+                for g in range(per_tap):
+                    real = min(4, s.channels - 4 * g)
+                    slots.append([si, r * dilation - pad, q * dilation - pad, s.c_base + 4 * g])
+                    cols.append((c_lo + 4 * g, real, r, q))
+                    n_slots += 1
+        while n_slots % (BK // 4):       # keep every 32-wide chunk inside one source
+            slots.append([si, 0, 0, -1])
+            cols.append((-1, 0, 0, 0))
+            n_slots += 1
+        c_lo += s.channels
+    k_pad = len(slots) * 4
+    w = torch.zeros(n_pad, k_pad)
+    wf = weight.float()
+    for j, (c0, real, r, q) in enumerate(cols):
+        if real:
+            w[:co, 4 * j:4 * j + real] = wf[:, c0:c0 + real, r, q]
+    b = torch.zeros(n_pad)
+    b[:co] = bias
+    return PackedConv(w, b, torch.tensor(slots, dtype=torch.int32), co, n_pad, k_pad, kh, stride, pad)
+
+
+@dataclass
+class PackedDcn:
+    weight: torch.Tensor   # [N_pad, 9*C]  k = tap*C + c
+    bias: torch.Tensor
+    n: int
+    n_pad: int
+    c: int
+
+    def to(self, device):
+        self.weight = self.weight.to(device).contiguous()
+        self.bias = self.bias.to(device).contiguous()
+        return self
+
+
+def pack_dcn(weight, bias) -> PackedDcn:
+    co, ci, kh, kw = weight.shape
+    assert (kh, kw) == (3, 3) and ci % BK == 0
+    n_pad = ((co + 31) // 32) * 32
+    w = torch.zeros(n_pad, 9 * ci)
+    w[:co] = weight.float().permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    b = torch.zeros(n_pad)
+    b[:co] = bias
+    return PackedDcn(w, b, co, n_pad, ci)
+
+
+def pack_upsample(weight):
+    """ConvTranspose2d depthwise weight (C,1,k,k) -> [k][k][C]."""
+    return weight.detach().float().cpu()[:, 0].permute(1, 2, 0).contiguous()

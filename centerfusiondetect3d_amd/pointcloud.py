@@ -1,0 +1,60 @@
+"""Drop-ins for the radar steps of the hot path, HIP-backed.
+
+  getPcFrustumHeatmap(output, pc_dep, calib, config)  <- utils/pointcloud.py:331-394
+  process_point_cloud_batch(...)                       <- dataset/generic_dataset.py:738-828
+  getAffineTransform(center, scale, 0, out_wh)         <- utils/image.py:43-83 (host, 3-point solve)
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def getPcFrustumHeatmap(output, pc_dep, calib, config):
+    """Same arguments / result as the reference: (B,3,H,W) map, zero where nothing was painted."""
+    K = int(config.MODEL.K)
+    B = pc_dep.shape[0]
+    _, inds, _ = ops.topk_peaks(output["heatmap"], K, nms=False)
+    return ops.frustum_assoc(inds, output["depth"], output["widthHeight"], output["dimension"],
+                             output["rotation"], calib.reshape(B, 3, 4).float(), pc_dep,
+                             float(config.DATASET.MAX_PC_DIST))
+
+
+def getAffineTransform(center, scale, rotateFactor, outputSize):
+    """Source-image -> output-map affine for rotation 0 (the inference path, detector.py:206-221)."""
+    if rotateFactor != 0:
+        raise NotImplementedError("rotation augmentation is training-only")
+    src_w = np.float32(scale)
+    dst_w, dst_h = outputSize
+    center = np.asarray(center, np.float32)
+    src = np.zeros((3, 2), np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    src[0] = center
+    src[1] = center + np.array([0, src_w * -0.5], np.float32)
+    dst[0] = np.array([dst_w * 0.5, dst_h * 0.5], np.float32)
+    dst[1] = dst[0] + np.array([0, dst_w * -0.5], np.float32)
+    for p in (src, dst):
+        d = p[0] - p[1]
+        p[2] = p[1] + np.array([-d[1], d[0]], np.float32)
+    A = np.concatenate([src.astype(np.float64), np.ones((3, 1))], axis=1)
+    return np.linalg.solve(A, dst.astype(np.float64)).T.copy()
+
+
+def process_point_cloud_batch(pc_2d_list, pc_3d_list, calibs, trans_out, out_hw, pillar_dims=(1.5, 0.2, 0.2),
+                              device="cuda", max_points=1024):
+    """Batched processPointCloud (PC_ROI_METHOD='pillars'): per-frame (3,N) / (R,N) float64 arrays
+    (already <= MAX_PC_DIST-filtered, image-projected and depth-sorted ascending, as
+    detector.py:262-283 leaves them) -> pc_dep (B,3,H,W) float32 on `device`."""
+    B = len(pc_2d_list)
+    n_rows = max(10, max(p.shape[0] for p in pc_3d_list))
+    max_n = max(1, max(p.shape[1] for p in pc_2d_list))
+    if max_n > max_points:
+        raise ValueError(f"{max_n} radar points in a frame exceeds the kernel limit {max_points}")
+    p2 = np.zeros((B, 3, max_n)); p3 = np.zeros((B, n_rows, max_n)); cnt = np.zeros(B, np.int32)
+    for b, (a, c) in enumerate(zip(pc_2d_list, pc_3d_list)):
+        n = a.shape[1]
+        p2[b, :, :n], p3[b, :c.shape[0], :n], cnt[b] = a[:3], c, n
+    calibs = np.asarray(calibs, np.float64).reshape(B, 3, 4)
+    trans = np.broadcast_to(np.asarray(trans_out, np.float64), (B, 2, 3)).copy()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return ops.pillar_expand(t(p2), t(p3), t(cnt), t(calibs), t(trans), out_hw, pillar_dims)

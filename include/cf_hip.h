@@ -1,0 +1,173 @@
+/* cf_hip.h - C ABI of libcfhip.so: the MI355X (gfx950) kernels of the CenterFusion forward path.
+ *
+ * The reference (HengWeiBin/CenterFusionDetect3D) is pure Python on PyTorch; its "FFI" for this
+ * path is the set of ATen / torchvision operators its modules dispatch to.  Each entry point below
+ * names the reference interface it replaces (paths relative to /root/reference/src/lib).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory unless marked "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launches are asynchronous;
+ *   - no hidden allocation, no host synchronisation, re-entrant per stream (graph-capturable);
+ *   - return value: 0 on success, negative CF_E* code on failure (never throws across the ABI);
+ *     cf_last_error() returns a static host string describing the last failure of this thread.
+ *   - activations between kernels are NHWC fp32 ("channels-last"); the module boundary tensors
+ *     (images in, head maps out) are NCHW fp32 as in the reference.
+ */
+#ifndef CF_HIP_H
+#define CF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CF_OK 0
+#define CF_EINVAL (-22)
+#define CF_ELAUNCH (-5)
+
+#define CF_MAX_SRC 4
+
+/* activation / epilogue modes of cf_conv2d_fused and cf_dcn_v2_fused */
+#define CF_ACT_NONE 0
+#define CF_ACT_RELU 1
+#define CF_ACT_SIGMOID_CLAMP 2 /* clamp(sigmoid(x), 1e-4, 1-1e-4)  (networks/detectHeads.py:21-23) */
+#define CF_ACT_RAW_AND_SIGDEPTH 3 /* out = x, out2 = 1/(sigmoid(x)+1e-6)-1 (model/utils.py:131-141) */
+
+#define CF_LAYOUT_NHWC 0
+#define CF_LAYOUT_NCHW 1
+
+/* One 16-byte K-slot of the implicit GEMM: 4 consecutive channels of one source at one tap. */
+typedef struct cf_slot {
+  int32_t src;   /* index into cf_conv_args.src (uniform inside a 32-wide K chunk); -1: zero chunk */
+  int32_t dy;    /* tap row offset relative to ho*stride (already includes -pad)                    */
+  int32_t dx;    /* tap col offset relative to wo*stride                                            */
+  int32_t c_off; /* first channel inside the source row; <0: zero padding slot                      */
+} cf_slot;
+
+/* cf_conv2d_fused: implicit-GEMM convolution on the fp32 MFMA pipe with a fused epilogue
+ *   out = act( conv(cat(src...), W) + bias [+ residual] )
+ * replaces aten::conv2d + aten::batch_norm(eval, folded into W/bias) + add_ + relu_ of
+ *   model/networks/dla.py:21-41 (Root: the channel concat is never materialised - up to 4 sources),
+ *   dla.py:124-161 (BasicBlock), dla.py:177-192,250-269 (stem/level0/level1), dla.py:98-103 (project),
+ *   dla.py:426-433 (conv_offset_mask), model/networks/detectHeads.py:59-98 (head convs) and
+ *   model/networks/fusionModules.py:18-35 (ConcateCombiner: feat || pc_hm as two sources).
+ * GEMM view: M = B*Ho*Wo, N = n_out, K = 4 * n_slots, weights pre-packed [N_pad][K_pad]
+ * (K contiguous, BN folded) in slot order by the host (centerfusiondetect3d_amd/packing.py). */
+typedef struct cf_conv_args {
+  const float* src[CF_MAX_SRC]; /* NHWC sources sharing B,H,W                                        */
+  int32_t src_c[CF_MAX_SRC];    /* channel stride (floats per pixel) of each source                  */
+  int32_t n_src;
+  int32_t B, H, W;              /* input geometry                                                     */
+  int32_t Ho, Wo;               /* output geometry                                                    */
+  int32_t stride;               /* spatial stride                                                     */
+  const float* weight;          /* [N_pad][K_pad]                                                     */
+  const cf_slot* slots;         /* [K_pad/4]                                                          */
+  const float* bias;            /* [N_pad]                                                            */
+  int32_t K_pad;                /* multiple of 32                                                     */
+  int32_t N;                    /* real output channels                                               */
+  int32_t N_pad;                /* multiple of 32, >= N                                               */
+  const float* residual;        /* optional NHWC [M][res_stride], added before the activation         */
+  int32_t res_stride;
+  float* out;                   /* NHWC: [M][out_stride] ; NCHW: [B][N][Ho*Wo]                        */
+  float* out2;                  /* second output for CF_ACT_RAW_AND_SIGDEPTH (same layout) or NULL    */
+  int32_t out_stride;           /* floats per pixel of the NHWC destination (>= N)                    */
+  int32_t out_layout;           /* CF_LAYOUT_*                                                        */
+  int32_t act;                  /* CF_ACT_*                                                           */
+} cf_conv_args;
+int cf_conv2d_fused(const cf_conv_args* a, void* stream);
+
+/* cf_dcn_v2_fused: modulated deformable 3x3 convolution (stride 1, pad 1, dil 1, groups 1) with
+ * the bilinear gather fused into the GEMM A-tile staging, + bias(BN folded) + ReLU.
+ * replaces torchvision.ops.deform_conv2d + BN + ReLU of model/networks/dla.py:456-472.
+ * `offmask` is the raw output of conv_offset_mask, NHWC with `om_stride` floats per pixel:
+ * channels 2k / 2k+1 = dy / dx of tap k, channels 18+k = mask logit of tap k (sigmoid applied
+ * here) - the chunk/cat of dla.py:457-459 is the identity on the first 18 channels. */
+typedef struct cf_dcn_args {
+  const float* x;       /* NHWC [B][H][W][C]                    */
+  const float* offmask; /* NHWC [B][H][W][om_stride], 27 used   */
+  int32_t om_stride;
+  int32_t B, H, W, C;   /* C multiple of 32                     */
+  const float* weight;  /* [N_pad][9*C], k = tap*C + c          */
+  const float* bias;    /* [N_pad]                              */
+  int32_t N, N_pad;
+  float* out;           /* NHWC [B][H][W][out_stride]           */
+  int32_t out_stride;
+  int32_t act;
+} cf_dcn_args;
+int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream);
+
+/* cf_upsample_dw: depthwise transposed conv (k = 2f, stride f, pad f/2, groups = C, no bias),
+ * optionally fused with the IDA skip add:  out = convT(x) [+ skip].
+ * replaces aten::conv_transpose2d + add of model/networks/dla.py:502-511, 518-524.
+ * weight is repacked [k][k][C]; all tensors NHWC; output is (H*f, W*f). */
+int cf_upsample_dw(const float* x, const float* weight, const float* skip, float* out, int B,
+                   int H, int W, int C, int f, void* stream);
+
+/* cf_maxpool2x2: 2x2 stride-2 max pooling, NHWC.  replaces aten::max_pool2d of dla.py:96,107. */
+int cf_maxpool2x2(const float* x, float* out, int B, int H, int W, int C, void* stream);
+
+/* cf_nchw_to_nhwc4: (B,3,H,W) NCHW image -> (B,H,W,4) NHWC with a zero 4th channel (stem input). */
+int cf_nchw_to_nhwc4(const float* x, float* out, int B, int C, int H, int W, void* stream);
+
+/* cf_nhwc_to_nchw: generic layout change used to hand NHWC intermediates back in NCHW. */
+int cf_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, int C, int c_stride,
+                    void* stream);
+
+/* cf_topk_peaks: per-image top-K over a (B,C,H,W) NCHW score map, optionally after the 3x3
+ * equality NMS, ordered by (score desc, class asc, pixel asc).
+ * replaces model/utils.py:6-38 (topk) [+ model/utils.py:112-128 (nms) when nms != 0].
+ * outputs: scores (B,K) f32, inds (B,K) i32 pixel index in [0,H*W), classes (B,K) i32.
+ * workspace: cf_topk_workspace_bytes(B) bytes. */
+size_t cf_topk_workspace_bytes(int B);
+int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
+                  int32_t* inds, int32_t* classes, void* workspace, void* stream);
+
+/* cf_frustum_assoc: radar frustum association for K peaks per image.
+ * replaces utils/pointcloud.py:331-394 (getPcFrustumHeatmap, after its topk) and 397-481
+ * (cvtPcDepthToHeatmap) incl. get_alpha / cvtAlphaToYaw / get3DCorners / getDistanceThresh
+ * (pointcloud.py:195-328).  All maps NCHW fp32.  pc_hm (B,3,H,W) is fully written (zero where
+ * nothing is painted); pc_hm_nhwc4 (B,H,W,4), if not NULL, receives the same data channels-last
+ * for the secondary-head convolution. */
+int cf_frustum_assoc(const int32_t* inds, int K, const float* depth, const float* wh,
+                     const float* dim, const float* rot, const float* calib, const float* pc_dep,
+                     int B, int H, int W, float max_pc_dist, float* pc_hm, float* pc_hm_nhwc4,
+                     void* stream);
+
+/* cf_pillar_expand: radar points -> pc_dep (B,3,H,W) by pillar expansion (fp64 geometry).
+ * replaces dataset/generic_dataset.py:738-942 (processPointCloud / transformPointCloud /
+ * getPcPillarsSize) + dataset/datasets/nuscenes.py:221-263 (getDepthMap / drawPcHeat).
+ * pc_2d: (B, 3, max_n) f64 [u, v, depth] in source-image pixels, depth-ascending per frame;
+ * pc_3d: (B, n_rows>=10, max_n) f64 camera-frame radar rows (row 8 = vx, row 9 = vz);
+ * counts: (B) i32 valid points per frame; calib (B,3,4) f64; trans (B,2,3) f64 (source image ->
+ * output map affine); pillar = (h, w, l) metres.  keep_mask (B,max_n) u8 and xy_out (B,2,max_n)
+ * f64 may be NULL; they receive the transformPointCloud filter mask / transformed coordinates. */
+int cf_pillar_expand(const double* pc_2d, const double* pc_3d, const int32_t* counts, int B,
+                     int max_n, int n_rows, const double* calib, const double* trans, int H, int W,
+                     double pillar_h, double pillar_w, double pillar_l, float* pc_dep,
+                     uint8_t* keep_mask, double* xy_out, void* stream);
+
+/* cf_decode_gather: from K (index, class, score) peaks produce the 33-float detection rows of
+ * model/decode.py:10-174 (fusionDecode): [score, classId, cx_n, cy_n, x1, y1, x2, y2, rot8, dim3,
+ * amodal2, att8, vel3, depth].  Any map pointer may be NULL (its columns are zero-filled; reg NULL
+ * means the +0.5 centre of decode.py:139-141).  det: (B,K,33) f32. */
+typedef struct cf_decode_args {
+  const float* scores;  /* (B,K) */
+  const int32_t* inds;  /* (B,K) */
+  const int32_t* classes;
+  const float *reg, *wh, *depth, *rot, *dim, *amodal, *att, *vel; /* NCHW maps */
+  int32_t B, K, H, W;
+  int32_t out_h, out_w; /* outputSize */
+  int32_t norm2d;
+  float* det;           /* (B,K,33) */
+} cf_decode_args;
+int cf_decode_gather(const cf_decode_args* a, void* stream);
+
+const char* cf_last_error(void);
+int cf_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CF_HIP_H */

@@ -1,0 +1,302 @@
+"""GPU parity, operator level: every C-ABI entry point against the CPU oracle on seeded inputs.
+fp32 GEMM-family kernels: rtol 1e-4 / atol 1e-4 (the north-star budget is 1e-3 end to end);
+index-path kernels (top-k, frustum, pillar, decode): bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dcn_ref, frustum_ref, decode_ref, pillar_ref
+from tests.golden import cases
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X box"
+    from centerfusiondetect3d_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def close(a, b, rtol=1e-4, atol=1e-4):
+    torch.testing.assert_close(a.cpu(), b, rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------------------------------ conv
+@pytest.mark.parametrize("B,Ci,Co,H,W,k,stride,act,res", [
+    (2, 16, 16, 40, 56, 3, 1, 1, False),     # level0-like, N_pad 32
+    (2, 16, 32, 40, 56, 3, 2, 1, False),     # level1 stride 2
+    (1, 64, 64, 28, 50, 3, 1, 1, True),      # BasicBlock conv2 + residual
+    (2, 128, 256, 14, 25, 3, 2, 1, False),   # 128-wide N tile, stride 2
+    (1, 512, 512, 7, 13, 3, 1, 1, True),     # small M, long K
+    (3, 64, 27, 23, 31, 3, 1, 0, False),     # conv_offset_mask (N=27), ragged M
+    (1, 256, 10, 16, 24, 1, 1, 0, False),    # head output 1x1
+])
+def test_conv2d_fused(dev, B, Ci, Co, H, W, k, stride, act, res):
+    from centerfusiondetect3d_amd import ops, packing
+    x, w, b = rnd(B, Ci, H, W, seed=1), rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5), rnd(Co, seed=3)
+    bn = (torch.rand(Co) + 0.5, rnd(Co, seed=4, scale=0.1), rnd(Co, seed=5, scale=0.1), torch.rand(Co) + 0.5)
+    ref = F.conv2d(x, w, b, stride, k // 2)
+    ref = F.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    r = rnd(*ref.shape, seed=6) if res else None
+    if res:
+        ref = ref + r
+    if act:
+        ref = F.relu(ref)
+    wf, bf = packing.fold_bn(w, b, bn)
+    pc = packing.pack_conv(wf, bf, [packing.Source(Ci, Ci)], stride=stride).to(dev)
+    out = ops.conv2d_fused(pc, [nhwc(x).to(dev)], B, H, W, act=act,
+                           residual=nhwc(r).to(dev) if res else None)
+    close(nchw(out), ref)
+
+
+def test_conv2d_multi_source_root_and_small_source(dev):
+    """Root: 1x1 over a never-materialised concat of 4 sources; secondary head: 3x3 over
+    feat(64) || pc_hm(3 channels stored with stride 4)."""
+    from centerfusiondetect3d_amd import ops, packing
+    B, H, W = 2, 14, 25
+    chans = [128, 128, 64, 128]
+    xs = [rnd(B, c, H, W, seed=10 + i) for i, c in enumerate(chans)]
+    w = rnd(128, sum(chans), 1, 1, seed=20, scale=sum(chans) ** -0.5)
+    ref = F.relu(F.conv2d(torch.cat(xs, 1), w))
+    pc = packing.pack_conv(w, torch.zeros(128), [packing.Source(c, c) for c in chans]).to(dev)
+    out = ops.conv2d_fused(pc, [nhwc(x).to(dev) for x in xs], B, H, W, act=1)
+    close(nchw(out), ref)
+
+    feat, pch = rnd(B, 64, H, W, seed=30), rnd(B, 3, H, W, seed=31)
+    w = rnd(256, 67, 3, 3, seed=32, scale=(67 * 9) ** -0.5)
+    b = rnd(256, seed=33)
+    ref = F.relu(F.conv2d(torch.cat([feat, pch], 1), w, b, 1, 1))
+    pc = packing.pack_conv(w, b, [packing.Source(64, 64), packing.Source(3, 4)]).to(dev)
+    pch4 = torch.cat([nhwc(pch), torch.full((B, H, W, 1), float("nan"))], dim=3)  # pad lane must be ignored... by zero weights
+    pch4 = torch.nan_to_num(pch4, nan=0.0)
+    out = ops.conv2d_fused(pc, [nhwc(feat).to(dev), pch4.to(dev)], B, H, W, act=1)
+    close(nchw(out), ref)
+
+
+def test_conv2d_stem_from_nchw_image_and_nchw_outputs(dev):
+    from centerfusiondetect3d_amd import ops, packing
+    B, H, W = 2, 32, 48
+    x = rnd(B, 3, H, W, seed=1)
+    w = rnd(16, 3, 7, 7, seed=2, scale=147 ** -0.5)
+    ref = F.relu(F.conv2d(x, w, None, 1, 3))
+    pc = packing.pack_conv(w, torch.zeros(16), [packing.Source(3, 4)]).to(dev)
+    x4 = ops.nchw_to_nhwc4(x.to(dev))
+    close(x4[..., :3], nhwc(x), 0, 0)
+    assert float(x4[..., 3].abs().max()) == 0.0
+    out = ops.conv2d_fused(pc, [x4], B, H, W, act=1)
+    close(nchw(out), ref)
+    close(ops.nhwc_to_nchw(out), ref)
+    # NCHW epilogues: plain, sigmoid-clamp, raw + sigmoid-depth; HoWo not a multiple of 4
+    for (hh, ww) in ((28, 50), (9, 7)):
+        f = rnd(B, 256, hh, ww, seed=3)
+        w1, b1 = rnd(10, 256, 1, 1, seed=4, scale=1 / 16), rnd(10, seed=5)
+        raw = F.conv2d(f, w1, b1)
+        pc1 = packing.pack_conv(w1, b1, [packing.Source(256, 256)]).to(dev)
+        fd = nhwc(f).to(dev)
+        close(ops.conv2d_fused(pc1, [fd], B, hh, ww, layout=1), raw)
+        close(ops.conv2d_fused(pc1, [fd], B, hh, ww, layout=1, act=2),
+              torch.clamp(torch.sigmoid(raw), 1e-4, 1 - 1e-4), 1e-5, 1e-6)
+        o1, o2 = ops.conv2d_fused(pc1, [fd], B, hh, ww, layout=1, act=3)
+        close(o1, raw)
+        close(o2, 1.0 / (torch.sigmoid(raw) + 1e-6) - 1.0, 1e-4, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------- dcn
+@pytest.mark.parametrize("B,Ci,Co,H,W,mag", [(2, 64, 64, 28, 50, 2.0), (1, 128, 64, 14, 25, 8.0),
+                                             (1, 512, 256, 7, 13, 1.0), (2, 256, 128, 9, 11, 30.0)])
+def test_dcn_v2_fused(dev, B, Ci, Co, H, W, mag):
+    from centerfusiondetect3d_amd import ops, packing
+    x = rnd(B, Ci, H, W, seed=1)
+    om = rnd(B, 27, H, W, seed=2)
+    om[:, :18] *= mag
+    w, b = rnd(Co, Ci, 3, 3, seed=3, scale=(Ci * 9) ** -0.5), rnd(Co, seed=4)
+    bn = (torch.rand(Co) + 0.5, rnd(Co, seed=5, scale=0.1), rnd(Co, seed=6, scale=0.1), torch.rand(Co) + 0.5)
+    o1, o2, m = torch.chunk(om, 3, dim=1)
+    ref = dcn_ref.deform_conv2d(x, torch.cat((o1, o2), 1), w, b, (1, 1), (1, 1), (1, 1), torch.sigmoid(m))
+    ref = F.relu(F.batch_norm(ref, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5))
+    wf, bf = packing.fold_bn(w, b, bn)
+    pd = packing.pack_dcn(wf, bf).to(dev)
+    om32 = torch.zeros(B, H, W, 32)
+    om32[..., :27] = nhwc(om)
+    out = ops.dcn_v2_fused(pd, nhwc(x).to(dev), om32.to(dev))
+    close(nchw(out), ref, 2e-4, 2e-4)
+
+
+def test_dcn_known_answers_on_device(dev):
+    """KATs run through the HIP kernel itself: zero offset/unit mask == conv2d; out of range == bias."""
+    from centerfusiondetect3d_amd import ops, packing
+    B, Ci, Co, H, W = 1, 64, 32, 12, 17
+    x, w, b = rnd(B, Ci, H, W, seed=1), rnd(Co, Ci, 3, 3, seed=2, scale=1 / 24), rnd(Co, seed=3)
+    pd = packing.pack_dcn(w, b).to(dev)
+    om = torch.zeros(B, H, W, 32)
+    om[..., 18:27] = 30.0                      # sigmoid(30) == 1.0f
+    out = ops.dcn_v2_fused(pd, nhwc(x).to(dev), om.to(dev), act=0)
+    close(nchw(out), F.conv2d(x, w, b, 1, 1))
+    om[..., :18] = 1000.0
+    out = ops.dcn_v2_fused(pd, nhwc(x).to(dev), om.to(dev), act=0)
+    close(nchw(out), b.view(1, Co, 1, 1).expand(B, Co, H, W), 0, 1e-6)
+
+
+# ----------------------------------------------------------------------------------- elementwise
+@pytest.mark.parametrize("f,C,H,W", [(2, 64, 14, 25), (4, 64, 7, 13), (2, 256, 5, 9)])
+def test_upsample_dw(dev, f, C, H, W):
+    from centerfusiondetect3d_amd import ops, packing
+    x, w = rnd(2, C, H, W, seed=1), rnd(C, 1, 2 * f, 2 * f, seed=2)
+    skip = rnd(2, C, H * f, W * f, seed=3)
+    ref = F.conv_transpose2d(x, w, None, stride=f, padding=f // 2, groups=C)
+    wk = packing.pack_upsample(w).to(dev)
+    close(nchw(ops.upsample_dw(nhwc(x).to(dev), wk, f)), ref, 1e-5, 1e-5)
+    close(nchw(ops.upsample_dw(nhwc(x).to(dev), wk, f, skip=nhwc(skip).to(dev))), ref + skip, 1e-5, 1e-5)
+
+
+def test_maxpool2x2(dev):
+    from centerfusiondetect3d_amd import ops
+    x = rnd(2, 32, 14, 26, seed=1)
+    close(nchw(ops.maxpool2x2(nhwc(x).to(dev))), F.max_pool2d(x, 2, 2), 0, 0)
+
+
+# ------------------------------------------------------------------------------------------ topk
+def _check_topk(dev, heat, K, nms):
+    from centerfusiondetect3d_amd import ops
+    ref_heat = decode_ref.nms(heat) if nms else heat
+    s, inds, cls, _, _ = frustum_ref.topk(ref_heat, K)
+    gs, gi, gc = ops.topk_peaks(heat.to(dev), K, nms=nms)
+    assert np.array_equal(gs.cpu().numpy(), s.numpy())
+    assert np.array_equal(gi.cpu().numpy(), inds.numpy())
+    assert np.array_equal(gc.cpu().numpy(), cls.numpy())
+
+
+@pytest.mark.parametrize("nms", [False, True])
+def test_topk_random_and_ties(dev, nms):
+    _check_topk(dev, cases.decode_case(0)["heatmap"], 100, nms)              # tie-free
+    _check_topk(dev, cases.decode_case(3, tie_heavy=True)["heatmap"], 100, nms)  # plateau + ties
+    flat = torch.full((2, 10, 112, 200), 1e-4)                               # everything ties
+    _check_topk(dev, flat, 100, nms)
+    _check_topk(dev, cases.frustum_case(1)[0]["heatmap"], 100, nms)
+
+
+def test_topk_overflow_path_and_odd_shapes(dev):
+    # > 4096 elements above the local-max bound: one thread's share holds all the large values
+    heat = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0)) * 0.1
+    flat = heat.view(-1)
+    flat[0::1024][:12] = 0.95            # stride-1024 lane 0 owns 12 huge values
+    big = torch.rand(6000, generator=torch.Generator().manual_seed(1)) * 0.3 + 0.5
+    idx = torch.randperm(flat.numel(), generator=torch.Generator().manual_seed(2))[:6000]
+    idx = idx[idx % 1024 < 90]           # only 90 distinct lanes hold the large values
+    flat[idx] = big[: idx.numel()]
+    _check_topk(dev, heat, 100, False)
+    _check_topk(dev, heat, 100, True)
+    for shape, K in (((1, 1, 5, 40), 100), ((3, 2, 17, 23), 7), ((1, 10, 224, 400), 100)):
+        h = torch.rand(*shape, generator=torch.Generator().manual_seed(3))
+        _check_topk(dev, h, K, False)
+        _check_topk(dev, h, K, True)
+    neg = rnd(2, 4, 20, 30, seed=9)      # negative scores order correctly too
+    _check_topk(dev, neg, 50, False)
+
+
+# --------------------------------------------------------------------------------------- frustum
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_frustum_bit_exact_vs_reference_golden(dev, golden_dir, seed):
+    from centerfusiondetect3d_amd import ops
+    g = np.load(os.path.join(golden_dir, f"frustum_{seed}.npz"))
+    y, pc_dep, calib = cases.frustum_case(seed)
+    d = {k: v.to(dev) for k, v in y.items()}
+    s, inds, cls = ops.topk_peaks(d["heatmap"], 100, nms=False)
+    assert np.array_equal(inds.cpu().numpy(), g["topk_inds"])
+    assert np.array_equal(cls.cpu().numpy(), g["topk_cls"])
+    assert np.array_equal(s.cpu().numpy(), g["topk_scores"])
+    pc_hm, hm4 = ops.frustum_assoc(inds, d["depth"], d["widthHeight"], d["dimension"], d["rotation"],
+                                   calib.to(dev), pc_dep.to(dev), 60.0, want_nhwc4=True)
+    flat = pc_hm.cpu().reshape(-1).numpy()
+    nz = np.nonzero(flat)[0]
+    assert np.array_equal(nz, g["nz_idx"])
+    assert np.array_equal(flat[nz], g["nz_val"])
+    assert np.array_equal(hm4[..., :3].cpu().numpy(), pc_hm.permute(0, 2, 3, 1).cpu().numpy())
+    assert float(hm4[..., 3].abs().max()) == 0.0
+
+
+def test_frustum_no_radar_and_single_box(dev):
+    from centerfusiondetect3d_amd import ops
+    y, pc_dep, calib = cases.frustum_case(5, B=1)
+    d = {k: v.to(dev) for k, v in y.items()}
+    _, inds, _ = ops.topk_peaks(d["heatmap"], 100)
+    out = ops.frustum_assoc(inds, d["depth"], d["widthHeight"], d["dimension"], d["rotation"],
+                            calib.to(dev), torch.zeros_like(pc_dep).to(dev))
+    assert float(out.abs().max()) == 0.0
+    ref = frustum_ref.pc_frustum_heatmap(y, pc_dep, calib, 1, 60.0)
+    _, inds1, _ = ops.topk_peaks(d["heatmap"], 1)
+    out = ops.frustum_assoc(inds1, d["depth"], d["widthHeight"], d["dimension"], d["rotation"],
+                            calib.to(dev), pc_dep.to(dev))
+    assert np.array_equal(out.cpu().numpy(), ref.numpy())
+
+
+# ---------------------------------------------------------------------------------------- decode
+@pytest.mark.parametrize("name,seed,radar,norm2d", [("decode_0.npz", 0, True, False),
+                                                    ("decode_1.npz", 1, False, False),
+                                                    ("decode_2_norm2d.npz", 2, True, True)])
+def test_decode_bit_exact_vs_reference_golden(dev, golden_dir, name, seed, radar, norm2d):
+    from centerfusiondetect3d_amd.decode import fusionDecode
+    g = np.load(os.path.join(golden_dir, name))
+    out = {k: v.to(dev) for k, v in cases.decode_case(seed, radar=radar).items()}
+    keys_before = set(out.keys())
+    det = fusionDecode([out], outputSize=(112, 200), K=100, norm2d=norm2d)
+    assert set(det.keys()) == set(g.files)
+    for k in g.files:
+        assert det[k].shape == g[k].shape, k
+        assert np.array_equal(det[k].cpu().numpy(), g[k]), k
+    # the reference renames rotation2 -> rotation in the caller's dict (decode.py:120-121)
+    if radar:
+        assert "rotation2" not in out and "rotation" in out
+    else:
+        assert set(out.keys()) == keys_before
+
+
+# ---------------------------------------------------------------------------------------- pillar
+def _pillar_batch(frames, max_n, dev):
+    B = len(frames)
+    p2 = np.zeros((B, 3, max_n)); p3 = np.zeros((B, 18, max_n)); cnt = np.zeros(B, np.int32)
+    cal = np.zeros((B, 3, 4)); tr = np.zeros((B, 2, 3))
+    for b, (a, c, k, t) in enumerate(frames):
+        n = a.shape[1]
+        p2[b, :, :n], p3[b, :, :n], cnt[b], cal[b], tr[b] = a, c, n, k, t
+    t = lambda a: torch.from_numpy(a).to(dev)
+    return t(p2), t(p3), t(cnt), t(cal), t(tr)
+
+
+@pytest.mark.parametrize("out_hw,img_wh", [((112, 200), (1600, 900)), ((224, 400), (1600, 900))])
+def test_pillar_expand_bit_exact_vs_oracle(dev, out_hw, img_wh):
+    from centerfusiondetect3d_amd import ops
+    rng = np.random.default_rng(0)
+    trans = pillar_ref.affine_transform_matrix((img_wh[0] / 2, img_wh[1] / 2), float(max(img_wh)),
+                                               (out_hw[1], out_hw[0]))
+    frames = []
+    for n in (0, 1, 37, 200, 600):
+        a, c, k = pillar_ref.synth_radar(rng, n)
+        frames.append((a, c, k, trans))
+    args = _pillar_batch(frames, 640, dev)
+    pc_dep, keep, xy = ops.pillar_expand(*args, out_hw, want_aux=True)
+    for b, (a, c, k, t) in enumerate(frames):
+        tp, p3, dm = pillar_ref.process_point_cloud(a, c, k, t, out_hw)
+        assert np.array_equal(pc_dep[b].cpu().numpy(), dm), f"frame {b}"
+        n = a.shape[1]
+        kb = keep[b, :n].cpu().numpy().astype(bool)
+        assert kb.sum() == tp.shape[1]
+        assert np.array_equal(xy[b, :, :n].cpu().numpy()[:, kb], tp[:2])
+        assert not keep[b, n:].any()
