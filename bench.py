@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py - CenterFusion forward throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch: images / pc_dep / calib already resident in HBM
+-> DLA-34 + DCNv2 neck + primary heads + frustum association + secondary heads (model.forward) ->
+NMS/top-k decode -> (N>1) RCCL all-gather of the (B,100,33) detections.  Workload = BASELINE
+configs[1]: Centerfusion_Middle, bs=16 per GPU, 3x448x800, <=200-point synthetic radar sweeps,
+random-init weights (no network for checkpoints).  Weak scaling: every rank runs its own 16 frames.
+
+Prints ONE JSON line on rank 0 (see the task contract); `roofline` is the dominant launch (the
+fused first layer of the 7 primary heads, 3x3 64->1792 over B*112*200 pixels: 28 % of all FLOPs)
+timed with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a port, not the
+reference) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "frames/sec/GPU CenterFusion forward, 3x448x800 bs=16; 1/2/4/8-GPU scaling"
+GFLOP_PER_FRAME = 167.49          # 2 x 83.74 GMAC (conv + DCN + offset conv + convT)
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+DOMINANT = "heads.primary.0"
+
+
+def synthetic_weights(model, seed=0, offset_std=0.01):
+    """default init, then BN stats/affine randomised and conv_offset_mask made
+    non-zero so the deformable gather really moves (offsets O(1-3 px))."""
+    g = torch.Generator().manual_seed(seed)
+    sd = model.state_dict()
+    for k, v in sd.items():
+        prefix, leaf = k.rsplit(".", 1)
+        is_bn = (prefix + ".running_mean") in sd
+        if is_bn and leaf == "running_mean":
+            v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+        elif is_bn and leaf == "running_var":
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        elif is_bn and leaf == "weight":
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        elif is_bn and leaf == "bias":
+            v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+        elif k.endswith("conv_offset_mask.weight"):
+            v.copy_(torch.randn(v.shape, generator=g) * offset_std)
+        elif k.endswith("conv_offset_mask.bias"):
+            v.copy_(torch.randn(v.shape, generator=g))
+    model.load_state_dict(sd)
+    return model
+
+
+def synthetic_radar(rng, n, max_dist=60.0, intr=(1266.4, 816.3, 491.5), img_wh=(1600, 900)):
+    """<=n radar returns in camera frame -> (pc_2d (3,M), pc_3d (18,M), calib (3,4)), filtered and
+    depth-sorted the way detector.py:262-283 hands them to processPointCloud."""
+    f, cx, cy = intr
+    z = rng.uniform(1.0, max_dist, n)
+    pc = np.zeros((18, n))
+    pc[0], pc[1], pc[2] = rng.uniform(-0.6, 0.6, n) * z, rng.uniform(-1.0, 1.0, n), z
+    pc[8], pc[9] = rng.normal(0, 5, n), rng.normal(0, 5, n)
+    u, v = f * pc[0] / z + cx, f * pc[1] / z + cy
+    m = (z > 0) & (u > 1) & (u < img_wh[0] - 1) & (v > 1) & (v < img_wh[1] - 1)
+    order = np.argsort(z[m])
+    pc_3d = pc[:, m][:, order]
+    pc_2d = np.stack([u[m][order], v[m][order], z[m][order]])
+    calib = np.array([[f, 0, cx, 0], [0, f, cy, 0], [0, 0, 1.0, 0]])
+    return pc_2d, pc_3d, calib
+
+
+def make_inputs(B, H, W, device, seed):
+    from centerfusiondetect3d_amd import getAffineTransform, process_point_cloud_batch
+    rng = np.random.default_rng(seed)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    images = torch.randn(B, 3, H, W, generator=g).to(device)
+    frames = [synthetic_radar(rng, int(rng.integers(50, 201))) for _ in range(B)]
+    trans = getAffineTransform((800.0, 450.0), 1600.0, 0, (W // 4, H // 4))
+    pc_dep = process_point_cloud_batch([f[0] for f in frames], [f[1] for f in frames],
+                                       [f[2] for f in frames], trans, (H // 4, W // 4), device=device)
+    calib = torch.tensor(np.stack([f[2] for f in frames]), dtype=torch.float32, device=device)
+    return images, pc_dep, calib
+
+
+def cpu_threads():
+    """Threads the CPU leg may use: the cgroup CPU quota if there is one (a 1-GPU box exposes 128
+    logical CPUs but grants ~16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("CF_CPU_THREADS", "16")))
+
+
+def cpu_baseline(H, W, frames=2, seed=0):
+    """CPU oracle (our torch-fp32 restatement, kind 'port') forward+decode on `frames` frames."""
+    from oracle import model_ref, decode_ref
+    sd = model_ref.make_state_dict(radar=True, seed=seed)
+    rs = np.random.RandomState(seed)
+    x = torch.from_numpy(rs.standard_normal((frames, 3, H, W)).astype(np.float32))
+    pc_dep = torch.zeros(frames, 3, H // 4, W // 4)
+    for b in range(frames):
+        for d in np.sort(rs.uniform(2, 58, 120)):
+            cx, cy = rs.randint(0, W // 4), rs.randint(2, H // 4)
+            pc_dep[b, 0, max(cy - 12, 0):cy, cx:cx + 2] = float(d)
+    calib = torch.tensor([[1266.4, 0, 816.3, 0], [0, 1266.4, 491.5, 0], [0, 0, 1, 0]]).repeat(frames, 1, 1)
+    cores = cpu_threads()
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        model_ref.forward(sd, x[:1], pc_dep=pc_dep[:1], calib=calib[:1])       # warm-up
+        t0 = time.perf_counter()
+        y = model_ref.forward(sd, x, pc_dep=pc_dep, calib=calib)
+        decode_ref.fusion_decode(y, (H // 4, W // 4), 100)
+        dt = time.perf_counter() - t0
+    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} frames 3x{H}x{W} (one bs={frames} forward+decode of the torch-fp32 "
+                      f"oracle after a 1-frame warm-up, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU")
+    ap.add_argument("--height", type=int, default=448)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from centerfusiondetect3d_amd import getModel, centerfusion_middle_config, decode_packed
+    from centerfusiondetect3d_amd.distributed import gather_detections, assume_equal_shards
+    assume_equal_shards(True)
+    B, H, W = args.batch, args.height, args.width
+    model = synthetic_weights(getModel(centerfusion_middle_config((H, W))), seed=0).to(dev).eval()
+    images, pc_dep, calib = make_inputs(B, H, W, dev, seed=1000 + rank)
+
+    def step():
+        out = model(images, pc_dep=pc_dep, calib=calib)
+        det, _ = decode_packed(out, (H // 4, W // 4), 100)
+        if world > 1:
+            det = gather_detections(det)
+        return det
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        model.time_launch(DOMINANT, True)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            det = step()
+        fence()
+        dt = time.perf_counter() - t0
+    launch_ms, launch_flops = model.launch_times(DOMINANT)
+    model.time_launch(DOMINANT, False)
+    assert det.shape == (B * world, 100, 33) and bool(torch.isfinite(det).all())
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        fps = world * B * args.steps / dt
+        avg_ms = float(np.mean(launch_ms))
+        achieved = launch_flops / (avg_ms * 1e-3) / 1e12
+        result = {
+            "metric": METRIC, "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"Centerfusion_Middle (DLA-34 + DCNv2 neck + pc_dep frustum fusion, 7+4 heads) "
+                                   f"forward + NMS/top-100 decode, bs={B}/GPU, 3x{H}x{W}, 50-200 radar pts/frame, "
+                                   f"random-init weights",
+                       "global_batch": B * world, "parallelism": f"dp{world} (batch shard, all-gather of detections)"},
+            "per_gpu_frames_per_s": round(fps / world, 2),
+            "model_tflops": round(fps * GFLOP_PER_FRAME * (H * W) / (448 * 800) / 1e3, 2),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None,
+                         "kernel": "conv_igemm_kernel<128,128,2,2> launch 'heads.primary.0' (3x3 64->1792)",
+                         "flop_per_launch": launch_flops, "avg_launch_ms": round(avg_ms, 4),
+                         "launches_timed": len(launch_ms)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(H, W, frames=args.cpu_frames)
+        elif world == 1:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,16 @@
+"""centerfusiondetect3d_amd - the CenterFusion inference forward path as hand-written HIP kernels
+for AMD MI355X (gfx950), behind the reference project's model / decode interfaces.
+
+    from centerfusiondetect3d_amd import getModel, fusionDecode, centerfusion_middle_config
+    model = getModel(centerfusion_middle_config()).cuda().eval()
+    outputs = model(images, pc_dep=pc_dep, calib=calib)      # [ {head: (B,C,112,200)} ]
+    dets = fusionDecode(outputs, outputSize=(112, 200), K=100)
+"""
+from .config import CfgNode, centerfusion_middle_config, centernet_config, update_heads
+from .model import DLASeg, getModel
+from .decode import fusionDecode, decode_packed, unpack_detections, DET_FIELDS, DET_WIDTH
+from .pointcloud import getPcFrustumHeatmap, getAffineTransform, process_point_cloud_batch
+
+__all__ = ["CfgNode", "centerfusion_middle_config", "centernet_config", "update_heads", "DLASeg",
+           "getModel", "fusionDecode", "decode_packed", "unpack_detections", "DET_FIELDS",
+           "DET_WIDTH", "getPcFrustumHeatmap", "getAffineTransform", "process_point_cloud_batch"]

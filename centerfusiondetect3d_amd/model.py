@@ -1,0 +1,572 @@
+"""`DLASeg`: the CenterFusion / CenterNet inference model on the MI355X HIP path.
+
+Drop-in boundary: same factory (`getModel(config)`, model/model.py:18-44), same
+`state_dict` key names and shapes as the reference's DLASeg (model/networks/dla.py:571-635 +
+base_model.py:30-53 + detectHeads.py:32-163), same call
+`model(images, pc_hm=None, pc_dep=None, calib=None) -> [dict]` (base_model.py:67-106) with the
+same keys, order, shapes and the `pc_hm_in` view of the caller's `pc_dep`
+(detectHeads.py:172).  Eval mode only - training is outside the hot path.
+
+Nothing else is shared with the reference's design.  The module is a parameter tree plus an
+*execution plan*: at first call for a given (B,H,W) it lays out every intermediate NHWC buffer in
+HBM once, folds BN into the conv weights, packs them into the implicit-GEMM layout, pre-builds the
+argument block of every kernel launch, and from then on a forward pass is a flat list of
+asynchronous launches on the current stream (no allocation except the returned head maps, no host
+sync, hipGraph-capturable).  There is no CPU fallback: without libcfhip.so / a GPU it raises.
+"""
+import ctypes as C
+import math
+from typing import Dict, List
+
+import torch
+from torch import nn
+
+from . import _lib, ops, packing
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, ACT_RAW_AND_SIGDEPTH, LAYOUT_NHWC,
+                   LAYOUT_NCHW)
+from .packing import Source
+
+SECONDARY_HEADS = ["velocity", "nuscenes_att", "depth2", "rotation2"]   # detectHeads.py:146-153
+CHANNELS = [16, 32, 64, 128, 256, 512]                                    # dla.py:303-307
+
+
+class _Scope(nn.Module):
+    """Empty container: only exists so parameters get the reference's dotted names."""
+
+
+def _register(root: nn.Module, dotted: str, tensor: torch.Tensor, buffer=False):
+    mod = root
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, _Scope())
+        mod = getattr(mod, p)
+    if buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+# ----------------------------------------------------------------------------- parameter spec
+def _conv_init(co, ci, k):
+    w = torch.empty(co, ci, k, k)
+    nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+    return w
+
+
+def _param_spec(config) -> List[tuple]:
+    """[(name, tensor, is_buffer)] in the reference's registration order."""
+    spec = []
+
+    def conv(name, co, ci, k, bias=False):
+        spec.append((name + ".weight", _conv_init(co, ci, k), False))
+        if bias:
+            bound = 1 / math.sqrt(ci * k * k)
+            spec.append((name + ".bias", torch.empty(co).uniform_(-bound, bound), False))
+
+    def bn(name, c):
+        spec.append((name + ".weight", torch.ones(c), False))
+        spec.append((name + ".bias", torch.zeros(c), False))
+        spec.append((name + ".running_mean", torch.zeros(c), True))
+        spec.append((name + ".running_var", torch.ones(c), True))
+        spec.append((name + ".num_batches_tracked", torch.tensor(0, dtype=torch.long), True))
+
+    conv("base.base_layer.0", 16, 3, 7); bn("base.base_layer.1", 16)
+    conv("base.level0.0", 16, 16, 3); bn("base.level0.1", 16)
+    conv("base.level1.0", 32, 16, 3); bn("base.level1.1", 32)
+
+    def block(p, ci, co):
+        conv(p + ".conv1", co, ci, 3); bn(p + ".bn1", co)
+        conv(p + ".conv2", co, co, 3); bn(p + ".bn2", co)
+
+    def tree1(p, ci, co, root_dim):
+        block(p + ".tree1", ci, co)
+        block(p + ".tree2", co, co)
+        conv(p + ".root.conv", co, root_dim, 1); bn(p + ".root.bn", co)
+        if ci != co:
+            conv(p + ".project.0", co, ci, 1); bn(p + ".project.1", co)
+
+    tree1("base.level2", 32, 64, 128)
+    for lvl, ci, co in ((3, 64, 128), (4, 128, 256)):
+        tree1(f"base.level{lvl}.tree1", ci, co, 2 * co)
+        tree1(f"base.level{lvl}.tree2", co, co, 3 * co + ci)
+    tree1("base.level5", 256, 512, 2 * 512 + 256)
+
+    def dcn(p, ci, co):
+        stdv = 1.0 / math.sqrt(ci * 9)
+        spec.append((p + ".weight", torch.empty(co, ci, 3, 3).uniform_(-stdv, stdv), False))
+        spec.append((p + ".bias", torch.zeros(co), False))
+        bn(p + ".activation.0", co)
+        spec.append((p + ".conv_offset_mask.weight", torch.zeros(27, ci, 3, 3), False))
+        spec.append((p + ".conv_offset_mask.bias", torch.zeros(27), False))
+
+    def up(p, c, f):
+        k = 2 * f
+        fl = math.ceil(k / 2)
+        cc = (2 * fl - 1 - fl % 2) / (2.0 * fl)
+        w = torch.zeros(c, 1, k, k)
+        for i in range(k):
+            for j in range(k):
+                w[:, 0, i, j] = (1 - abs(i / fl - cc)) * (1 - abs(j / fl - cc))
+        spec.append((p + ".weight", w, False))
+
+    def ida(p, o, srcs, fs):
+        for n in range(1, len(srcs)):
+            dcn(f"{p}.proj_{n}", srcs[n], o)
+            up(f"{p}.up_{n}", o, fs[n])
+            dcn(f"{p}.node_{n}", o, o)
+
+    chans = CHANNELS[2:]
+    in_ch = list(chans)
+    for i in range(3):
+        j = -i - 2
+        ida(f"dla_up.ida_{i}", chans[j], in_ch[j:], [1] + [2] * (len(in_ch[j:]) - 1))
+        in_ch[j + 1:] = [chans[j]] * len(in_ch[j + 1:])
+    ida("ida_up", 64, [64, 128, 256], [1, 2, 4])
+
+    radar_middle = bool(config.DATASET.RADAR_PC) and config.MODEL.FUSION_STRATEGY == "middle"
+
+    def head_conv_layer(name, co, ci, k, zero_bias, bias_fill=None):
+        spec.append((name + ".weight", _conv_init(co, ci, k), False))
+        bound = 1 / math.sqrt(ci * k * k)
+        b = torch.zeros(co) if zero_bias else torch.empty(co).uniform_(-bound, bound)
+        if bias_fill is not None:
+            b.fill_(bias_fill)
+        spec.append((name + ".bias", b, False))
+
+    for h, n_out in config.heads.items():
+        hc = list(config.head_conv[h])
+        cin = 67 if (radar_middle and h in SECONDARY_HEADS) else 64
+        p = f"detectHead_0.{h}"
+        zero = h != "heatmap"                     # initConv2dWeights: bias 0 on non-heatmap heads
+        head_conv_layer(p + ".0", hc[0], cin, 3, zero)
+        idx = 2
+        for i in range(1, len(hc)):
+            head_conv_layer(f"{p}.{idx}", hc[i], hc[i - 1], 1, zero)
+            idx += 2
+        head_conv_layer(f"{p}.{idx}", n_out, hc[-1], 1, zero,
+                        -4.6 if h == "heatmap" else None)      # detectHeads.py:93
+    return spec
+
+
+# ----------------------------------------------------------------------------- execution plan
+class _Plan:
+    """Buffers + pre-built launch list for one (B, H, W, device)."""
+
+    def __init__(self, model: "DLASeg", B, H, W, device):
+        self.B, self.H, self.W, self.device = B, H, W, device
+        self.lib = _lib.load()
+        self.steps = []          # (fn, args...) tuples executed in order (stream appended at run)
+        self.keep = []           # keeps arg blocks / buffers alive
+        self.bytes = 0
+        self.step_index = {}     # conv name -> index in self.steps
+        self.step_flops = {}     # conv name -> algorithmic FLOPs of that launch (2*MACs)
+        self.timed = {}          # step index -> [(start_event, end_event)] filled while timing is on
+        pk = model._packed
+        cfg = model.config
+        heads, head_conv = dict(cfg.heads), {k: list(v) for k, v in cfg.head_conv.items()}
+        radar = model.isRadarEnabled and model.fusionStrategy == "middle"
+        K = int(cfg.MODEL.K)
+
+        def buf(*shape, dtype=torch.float32):
+            t = torch.empty(shape, device=device, dtype=dtype)
+            self.bytes += t.numel() * t.element_size()
+            self.keep.append(t)
+            return t
+
+        def conv(name, srcs, h, w, act=ACT_RELU, residual=None, out=None, out_stride=None,
+                 out_offset=0, layout=LAYOUT_NHWC, out2=None, strides=None):
+            pc = pk[name]
+            ho = (h + 2 * pc.pad - pc.kh) // pc.stride + 1
+            wo = (w + 2 * pc.pad - pc.kh) // pc.stride + 1
+            if out is None:
+                out = buf(B, ho, wo, pc.n)
+            a = ops.conv_args(pc, srcs, strides or [s.shape[-1] for s in srcs], B, h, w, out,
+                              out_stride or pc.n, act, residual,
+                              residual.shape[-1] if residual is not None else 0, layout, out2,
+                              out_offset)
+            self.keep.append(a)
+            self.step_index[name] = len(self.steps)
+            self.step_flops[name] = 2.0 * B * ho * wo * pc.n * (pc.kh * pc.kh * sum(
+                int(c) for c in pc.real_cin))
+            self.steps.append((self.lib.cf_conv2d_fused, C.byref(a)))
+            return out, a
+
+        def pool(x):
+            _, h, w, c = x.shape
+            o = buf(B, h // 2, w // 2, c)
+            self.steps.append((self.lib.cf_maxpool2x2, x.data_ptr(), o.data_ptr(), B, h, w, c))
+            return o
+
+        def block(p, x, residual):
+            _, h, w, _ = x.shape
+            t, _ = conv(p + ".conv1", [x], h, w)
+            _, ho, wo, _ = t.shape
+            o, _ = conv(p + ".conv2", [t], ho, wo, residual=residual if residual is not None else x)
+            return o
+
+        def tree(p, levels, x, stride, level_root, children=None):
+            children = [] if children is None else children
+            bottom = pool(x) if stride > 1 else x
+            if (p + ".project") in pk:
+                _, h, w, _ = bottom.shape
+                residual, _ = conv(p + ".project", [bottom], h, w, act=ACT_NONE)
+            else:
+                residual = bottom
+            if level_root:
+                children.append(bottom)
+            if levels == 1:
+                x1 = block(p + ".tree1", x, residual)
+                x2 = block(p + ".tree2", x1, None)
+                _, h, w, _ = x2.shape
+                o, _ = conv(p + ".root", [x2, x1, *children], h, w)
+                return o
+            x1 = tree(p + ".tree1", levels - 1, x, stride, False)
+            children.append(x1)
+            return tree(p + ".tree2", levels - 1, x1, 1, False, children)
+
+        def dcn_node(p, x):
+            _, h, w, c = x.shape
+            om = buf(B, h, w, 32)
+            conv(p + ".conv_offset_mask", [x], h, w, act=ACT_NONE, out=om, out_stride=32)
+            pd = pk[p]
+            o = buf(B, h, w, pd.n)
+            a = ops.dcn_args(pd, x, om, 32, B, h, w, o, pd.n, ACT_RELU)
+            self.keep.append(a)
+            self.step_index[p] = len(self.steps)
+            self.step_flops[p] = 2.0 * B * h * w * pd.n * 9 * pd.c
+            self.steps.append((self.lib.cf_dcn_v2_fused, C.byref(a)))
+            return o
+
+        def ida(p, layers, startp, endp):
+            for i in range(startp + 1, endp):
+                j = i - startp
+                proj = dcn_node(f"{p}.proj_{j}", layers[i])
+                wk, f = pk[f"{p}.up_{j}"]
+                _, h, w, c = proj.shape
+                summed = buf(B, h * f, w * f, c)          # up(proj(x)) + skip, fused
+                self.steps.append((self.lib.cf_upsample_dw, proj.data_ptr(), wk.data_ptr(),
+                                   layers[i - 1].data_ptr(), summed.data_ptr(), B, h, w, c, f))
+                layers[i] = dcn_node(f"{p}.node_{j}", summed)
+
+        # ---- backbone
+        self.x4 = buf(B, H, W, 4)
+        self.in_step = len(self.steps)
+        self.steps.append(None)                            # nchw_to_nhwc4(images): patched per call
+        t, _ = conv("base.base_layer", [self.x4], H, W)
+        y0, _ = conv("base.level0", [t], H, W)
+        y1, _ = conv("base.level1", [y0], H, W)
+        layers = [y0, y1]
+        x = y1
+        for lvl, levels, root in ((2, 1, False), (3, 2, True), (4, 2, True), (5, 1, True)):
+            x = tree(f"base.level{lvl}", levels, x, 2, root)
+            layers.append(x)
+        self.debug = {f"y{i}": t for i, t in enumerate(layers)}   # NHWC stage outputs (tests only)
+        # ---- DLA-up + IDA-up neck
+        out = [layers[-1]]
+        for i in range(len(layers) - 2 - 1):
+            ida(f"dla_up.ida_{i}", layers, len(layers) - i - 2, len(layers))
+            out.insert(0, layers[-1])
+        for i, t in enumerate(out):
+            self.debug[f"up{i}"] = t
+        y = out[:3]
+        ida("ida_up", y, 0, 3)
+        feat = y[-1]
+        self.feat = feat
+        _, h4, w4, _ = feat.shape
+        self.h4, self.w4 = h4, w4
+
+        # ---- heads.  Per-call output tensors are patched into these arg blocks (self.outs).
+        self.outs: Dict[str, List] = {}                    # head -> [(argblock, field)]
+        primary = [h for h in heads if not (radar and h in SECONDARY_HEADS)]
+        self.primary = primary
+        hid, _ = conv("heads.primary.0", [feat], h4, w4)   # (B,h4,w4,256*len(primary))
+        hs = hid.shape[-1]
+
+        def head_out(h, src, src_stride):
+            act = ACT_SIGMOID_CLAMP if h == "heatmap" else (
+                ACT_RAW_AND_SIGDEPTH if h in ("depth", "depth2") else ACT_NONE)
+            pc = pk[f"heads.{h}.out"]
+            a = ops.conv_args(pc, [src], [src_stride], B, h4, w4, src, 0, act, None, 0,
+                              LAYOUT_NCHW, src if act == ACT_RAW_AND_SIGDEPTH else None)
+            self.keep.append(a)
+            self.step_index[f"heads.{h}.out"] = len(self.steps)
+            self.step_flops[f"heads.{h}.out"] = 2.0 * B * h4 * w4 * pc.n * 256
+            self.steps.append((self.lib.cf_conv2d_fused, C.byref(a)))
+            self.outs[h] = a
+
+        for h in primary:
+            head_out(h, hid, hs)
+        self.radar = radar
+        self.K = K
+        if radar:
+            self.tk_scores = buf(B, K)
+            self.tk_inds = buf(B, K, dtype=torch.int32)
+            self.tk_cls = buf(B, K, dtype=torch.int32)
+            self.pc_hm4 = buf(B, h4, w4, 4)
+            self.topk_step = len(self.steps); self.steps.append(None)
+            self.frustum_step = len(self.steps); self.steps.append(None)
+            s1, _ = conv("heads.secondary.0", [feat, self.pc_hm4], h4, w4)     # (B,h4,w4,1024)
+            ss = s1.shape[-1]
+            s2 = buf(B, h4, w4, ss)
+            for n, h in enumerate(SECONDARY_HEADS):
+                conv(f"heads.{h}.2", [s1], h4, w4, out=s2, out_stride=ss, out_offset=256 * n, strides=[ss])
+                conv(f"heads.{h}.4", [s2], h4, w4, out=s1, out_stride=ss, out_offset=256 * n, strides=[ss])
+                head_out(h, s1, ss)
+
+    # ------------------------------------------------------------------------------------------
+    def run(self, model, x, pc_dep, calib):
+        B, H, W, dev = self.B, self.H, self.W, self.device
+        lib = self.lib
+        st = _lib.stream_ptr()
+        h4, w4 = self.h4, self.w4
+        heads = model.config.heads
+        y = {}
+        new = lambda c: torch.empty((B, c, h4, w4), device=dev, dtype=torch.float32)
+        for h in self.primary:
+            t = new(heads[h])
+            y[h] = t
+            self.outs[h].out = t.data_ptr()
+        depth_raw = y["depth"]                             # raw logits; "depth" gets the sigmoid form
+        y["depthMap"] = depth_raw
+        y["depth"] = new(1)
+        self.outs["depth"].out2 = y["depth"].data_ptr()
+        y["calib"] = calib
+        self.steps[self.in_step] = (lib.cf_nchw_to_nhwc4, x.data_ptr(), self.x4.data_ptr(), B, 3, H, W)
+        if self.radar:
+            pc_hm = new(3)
+            self.steps[self.topk_step] = (lib.cf_topk_peaks, y["heatmap"].data_ptr(), B, heads["heatmap"],
+                                          h4, w4, self.K, 0, self.tk_scores.data_ptr(),
+                                          self.tk_inds.data_ptr(), self.tk_cls.data_ptr(), None)
+            self.steps[self.frustum_step] = (
+                lib.cf_frustum_assoc, self.tk_inds.data_ptr(), self.K, y["depth"].data_ptr(),
+                y["widthHeight"].data_ptr(), y["dimension"].data_ptr(), y["rotation"].data_ptr(),
+                calib.data_ptr(), pc_dep.data_ptr(), B, h4, w4,
+                C.c_float(float(model.config.DATASET.MAX_PC_DIST)), pc_hm.data_ptr(),
+                self.pc_hm4.data_ptr())
+            y["pc_hm_in"] = pc_dep[:, :1]
+            y["pc_hm"] = pc_hm[:, 0, :, :].unsqueeze(1)
+            for h in SECONDARY_HEADS:
+                t = new(heads[h])
+                y[h] = t
+                self.outs[h].out = t.data_ptr()
+            y["pc_hm_out"] = pc_hm[:, :1]
+            y["depthMap"] = y["depth2"]                    # raw depth2 logits (detectHeads.py:188-190)
+            y["depth2"] = new(1)
+            self.outs["depth2"].out2 = y["depth2"].data_ptr()
+        if self.timed:
+            for i, step in enumerate(self.steps):
+                ev = self.timed.get(i)
+                if ev is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                rc = step[0](*step[1:], st)
+                if ev is not None:
+                    e1.record()
+                    ev.append((e0, e1))
+                if rc != 0:
+                    _lib.check(rc, step[0].__name__)
+            return [y]
+        for step in self.steps:
+            rc = step[0](*step[1:], st)
+            if rc != 0:
+                _lib.check(rc, step[0].__name__)
+        return [y]
+
+
+# ----------------------------------------------------------------------------------- the module
+class DLASeg(nn.Module):
+    def __init__(self, num_layers, in_channels, config):
+        super().__init__()
+        if str(num_layers) != "34":
+            raise NotImplementedError("only DLA-34 is implemented (the reference ships nothing else)")
+        if in_channels != 3:
+            raise NotImplementedError("early fusion (radar channels in the image) is outside the hot path")
+        if config.MODEL.DLA.NODE != "DeformConv":
+            raise NotImplementedError("MODEL.DLA.NODE must be DeformConv (the only node type that works upstream)")
+        if getattr(config.DATASET, "ONE_HOT_PC", False):
+            raise NotImplementedError("ONE_HOT_PC is outside the hot path")
+        self.config = config
+        self.heads = config.heads
+        self.isRadarEnabled = bool(config.DATASET.RADAR_PC)
+        self.fusionStrategy = config.MODEL.FUSION_STRATEGY if self.isRadarEnabled else None
+        if self.fusionStrategy not in (None, "middle"):
+            raise NotImplementedError(f"fusion strategy {self.fusionStrategy!r} is outside the hot path")
+        if self.isRadarEnabled and not config.MODEL.FRUSTUM:
+            raise NotImplementedError("middle fusion without frustum association is outside the hot path")
+        try:                                               # dla.py:578-580
+            config.defrost()
+            config.MODEL.PYRAMID_OUT_SIZE = [config.MODEL.OUTPUT_SIZE]
+            config.freeze()
+        except Exception:
+            pass
+        for name, tensor, is_buf in _param_spec(config):
+            _register(self, name, tensor, is_buf)
+        self._packed = None
+        self._plans = {}
+        self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
+        self.eval()
+
+    # weights changed (load_state_dict / .to()) -> re-pack lazily
+    def invalidate(self):
+        self._packed = None
+        self._plans = {}
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    # ------------------------------------------------------------------------------ weight prep
+    def _prepare(self, device):
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        pk = {}
+
+        def bn(p):
+            return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"])
+
+        def conv_bn(name, wkey, bnkey, sources, stride=1, bias=None):
+            w, b = packing.fold_bn(sd[wkey], bias, bn(bnkey) if bnkey else None)
+            pk[name] = packing.pack_conv(w, b, sources, stride=stride).to(device)
+
+        conv_bn("base.base_layer", "base.base_layer.0.weight", "base.base_layer.1", [Source(3, 4)])
+        conv_bn("base.level0", "base.level0.0.weight", "base.level0.1", [Source(16, 16)])
+        conv_bn("base.level1", "base.level1.0.weight", "base.level1.1", [Source(16, 16)], stride=2)
+
+        def tree1(p, ci, co, root_srcs):
+            conv_bn(p + ".tree1.conv1", p + ".tree1.conv1.weight", p + ".tree1.bn1", [Source(ci, ci)],
+                    stride=2 if ci != co else 1)
+            conv_bn(p + ".tree1.conv2", p + ".tree1.conv2.weight", p + ".tree1.bn2", [Source(co, co)])
+            conv_bn(p + ".tree2.conv1", p + ".tree2.conv1.weight", p + ".tree2.bn1", [Source(co, co)])
+            conv_bn(p + ".tree2.conv2", p + ".tree2.conv2.weight", p + ".tree2.bn2", [Source(co, co)])
+            conv_bn(p + ".root", p + ".root.conv.weight", p + ".root.bn", [Source(c, c) for c in root_srcs])
+            if (p + ".project.0.weight") in sd:
+                conv_bn(p + ".project", p + ".project.0.weight", p + ".project.1", [Source(ci, ci)])
+
+        tree1("base.level2", 32, 64, [64, 64])
+        for lvl, ci, co in ((3, 64, 128), (4, 128, 256)):
+            tree1(f"base.level{lvl}.tree1", ci, co, [co, co])
+            tree1(f"base.level{lvl}.tree2", co, co, [co, co, ci, co])
+        tree1("base.level5", 256, 512, [512, 512, 256])
+
+        def dcn(p, ci, co):
+            w, b = packing.fold_bn(sd[p + ".weight"], sd[p + ".bias"], bn(p + ".activation.0"))
+            pk[p] = packing.pack_dcn(w, b).to(device)
+            pk[p + ".conv_offset_mask"] = packing.pack_conv(
+                sd[p + ".conv_offset_mask.weight"].float().cpu(),
+                sd[p + ".conv_offset_mask.bias"].float().cpu(), [Source(ci, ci)]).to(device)
+
+        def ida(p, o, srcs, fs):
+            for n in range(1, len(srcs)):
+                dcn(f"{p}.proj_{n}", srcs[n], o)
+                dcn(f"{p}.node_{n}", o, o)
+                pk[f"{p}.up_{n}"] = (packing.pack_upsample(sd[f"{p}.up_{n}.weight"]).to(device), fs[n])
+
+        chans = CHANNELS[2:]
+        in_ch = list(chans)
+        for i in range(3):
+            j = -i - 2
+            ida(f"dla_up.ida_{i}", chans[j], in_ch[j:], [1] + [2] * (len(in_ch[j:]) - 1))
+            in_ch[j + 1:] = [chans[j]] * len(in_ch[j + 1:])
+        ida("ida_up", 64, [64, 128, 256], [1, 2, 4])
+
+        # heads: sibling first layers share their input -> one GEMM with concatenated outputs
+        heads = dict(self.config.heads)
+        head_conv = {k: list(v) for k, v in self.config.head_conv.items()}
+        radar = self.isRadarEnabled and self.fusionStrategy == "middle"
+        hp = "detectHead_0"
+        primary = [h for h in heads if not (radar and h in SECONDARY_HEADS)]
+        for h in heads:
+            if any(c != 256 for c in head_conv[h]):
+                raise NotImplementedError("head_conv widths other than 256 are not on the path")
+        w = torch.cat([sd[f"{hp}.{h}.0.weight"].float().cpu() for h in primary], 0)
+        b = torch.cat([sd[f"{hp}.{h}.0.bias"].float().cpu() for h in primary], 0)
+        pk["heads.primary.0"] = packing.pack_conv(w, b, [Source(64, 64)]).to(device)
+        for n, h in enumerate(primary):
+            assert len(head_conv[h]) == 1
+            pk[f"heads.{h}.out"] = packing.pack_conv(
+                sd[f"{hp}.{h}.2.weight"].float().cpu(), sd[f"{hp}.{h}.2.bias"].float().cpu(),
+                [Source(256, 256 * len(primary), 256 * n)]).to(device)
+        if radar:
+            w = torch.cat([sd[f"{hp}.{h}.0.weight"].float().cpu() for h in SECONDARY_HEADS], 0)
+            b = torch.cat([sd[f"{hp}.{h}.0.bias"].float().cpu() for h in SECONDARY_HEADS], 0)
+            pk["heads.secondary.0"] = packing.pack_conv(w, b, [Source(64, 64), Source(3, 4)]).to(device)
+            ns = 256 * len(SECONDARY_HEADS)
+            for n, h in enumerate(SECONDARY_HEADS):
+                assert len(head_conv[h]) == 3
+                for idx in (2, 4):
+                    pk[f"heads.{h}.{idx}"] = packing.pack_conv(
+                        sd[f"{hp}.{h}.{idx}.weight"].float().cpu(), sd[f"{hp}.{h}.{idx}.bias"].float().cpu(),
+                        [Source(256, ns, 256 * n)]).to(device)
+                pk[f"heads.{h}.out"] = packing.pack_conv(
+                    sd[f"{hp}.{h}.6.weight"].float().cpu(), sd[f"{hp}.{h}.6.bias"].float().cpu(),
+                    [Source(256, ns, 256 * n)]).to(device)
+        self._packed = pk
+
+    # ----------------------------------------------------------------------------------- forward
+    def forward(self, x, pc_hm=None, pc_dep=None, calib=None):
+        if self.training:
+            raise NotImplementedError("training is outside the hot path; call model.eval()")
+        if not x.is_cuda:
+            raise _lib.CfHipError("DLASeg.forward needs device tensors: the HIP path has no CPU fallback")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 32 or x.shape[3] % 32:
+            raise ValueError(f"images must be (B,3,H,W) with H,W multiples of 32, got {tuple(x.shape)}")
+        B, _, H, W = x.shape
+        dev = x.device
+        x = x.float().contiguous()
+        if self.isRadarEnabled:
+            if pc_dep is None or calib is None:
+                raise ValueError("radar model: pc_dep and calib are required")
+            if tuple(pc_dep.shape) != (B, 3, H // 4, W // 4):
+                raise ValueError(f"pc_dep must be {(B, 3, H // 4, W // 4)}, got {tuple(pc_dep.shape)}")
+            if pc_dep.dtype != torch.float32 or not pc_dep.is_contiguous():
+                raise ValueError("pc_dep must be contiguous float32")
+            calib = calib.reshape(B, 3, 4).float().contiguous()
+        if self._packed is None:
+            self._prepare(dev)
+        key = (B, H, W, dev)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = _Plan(self, B, H, W, dev)
+        with torch.cuda.device(dev):
+            return plan.run(self, x, pc_dep, calib)
+
+
+    # ------------------------------------------------------------------------- instrumentation
+    def time_launch(self, name, on=True):
+        """Bracket the named conv launch with HIP events (recorded on the launch stream) in every
+        existing plan; read back with launch_times().  Names: 'heads.primary.0', 'base.level0', ..."""
+        for plan in self._plans.values():
+            idx = plan.step_index[name]
+            if on:
+                plan.timed.setdefault(idx, [])
+            else:
+                plan.timed.pop(idx, None)
+
+    def launch_times(self, name):
+        """-> (list of ms per recorded launch, algorithmic FLOPs of one launch); syncs."""
+        torch.cuda.synchronize()
+        out, flops = [], 0.0
+        for plan in self._plans.values():
+            idx = plan.step_index[name]
+            flops = plan.step_flops[name]
+            for e0, e1 in plan.timed.get(idx, []):
+                out.append(e0.elapsed_time(e1))
+            if idx in plan.timed:
+                plan.timed[idx] = []
+        return out, flops
+
+    def conv_flops_per_forward(self):
+        """Algorithmic FLOPs (2*MACs) of all conv / DCN launches of the newest plan."""
+        plan = list(self._plans.values())[-1]
+        return sum(plan.step_flops.values())
+
+
+_network_factory = {"dla": DLASeg}
+
+
+def getModel(config):
+    """model/model.py:18-44."""
+    arch = config.MODEL.ARCH
+    num_layers = arch[arch.find("_") + 1:] if "_" in arch else 0
+    arch = arch[:arch.find("_")] if "_" in arch else arch
+    return _network_factory[arch](num_layers, in_channels=3, config=config)

@@ -48,6 +48,7 @@ class PackedConv:
     kh: int
     stride: int
     pad: int
+    real_cin: tuple = ()      # real input channels per source (for FLOP accounting)
 
     def to(self, device):
         self.weight = self.weight.to(device).contiguous()
@@ -89,7 +90,8 @@ def pack_conv(weight, bias, sources: Sequence[Source], stride=1, pad=None, dilat
             w[:co, 4 * j:4 * j + real] = wf[:, c0:c0 + real, r, q]
     b = torch.zeros(n_pad)
     b[:co] = bias
-    return PackedConv(w, b, torch.tensor(slots, dtype=torch.int32), co, n_pad, k_pad, kh, stride, pad)
+    return PackedConv(w, b, torch.tensor(slots, dtype=torch.int32), co, n_pad, k_pad, kh, stride, pad,
+                      tuple(s.channels for s in sources))
 
 
 @dataclass
