@@ -19,14 +19,15 @@ class ConvArgs(C.Structure):
                 ("Wo", C.c_int32), ("stride", C.c_int32), ("weight", _f), ("slots", _f),
                 ("bias", _f), ("K_pad", C.c_int32), ("N", C.c_int32), ("N_pad", C.c_int32),
                 ("residual", _f), ("res_stride", C.c_int32), ("out", _f), ("out2", _f),
-                ("out_stride", C.c_int32), ("out_layout", C.c_int32), ("act", C.c_int32)]
+                ("out_stride", C.c_int32), ("out_layout", C.c_int32), ("act", C.c_int32),
+                ("precise", C.c_int32)]
 
 
 class DcnArgs(C.Structure):
     _fields_ = [("x", _f), ("offmask", _f), ("om_stride", C.c_int32), ("B", C.c_int32),
                 ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("weight", _f), ("bias", _f),
                 ("N", C.c_int32), ("N_pad", C.c_int32), ("out", _f), ("out_stride", C.c_int32),
-                ("act", C.c_int32)]
+                ("act", C.c_int32), ("precise", C.c_int32)]
 
 
 class DecodeArgs(C.Structure):

@@ -46,10 +46,16 @@ struct DcnK {
   EpilogueArgs ep;
 };
 
-template <int TM, int TN>
+// One 32-deep K chunk.  PRECISE: the chunk is summed into a fresh accumulator (first MFMA takes
+// C = 0) and only then added to the running sum, i.e. two-level (blocked) summation: rounding error
+// grows with sqrt(32) + sqrt(K/32) instead of sqrt(K).  A bare fp32 MFMA chain over K = 4608 is
+// ~4x less accurate than the CPU reference's blocked accumulation, and the DCN neck amplifies
+// upstream rounding ~100x (tools/stage_error.py), so everything feeding the neck runs PRECISE.
+template <int TM, int TN, bool PRECISE>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const float* __restrict__ Bs,
                                           int a_row0, int b_row0, int lane, f32x16 (&acc)[TM][TN]) {
   const int li = lane & 31, h = lane >> 5;
+  f32x16 part[TM][TN];
 #pragma unroll
   for (int ks = 0; ks < CF_BK / 8; ++ks) {
     f32x4 a[TM], b[TN];
@@ -64,8 +70,24 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, const fl
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][t], b[tn][t], acc[tm][tn], 0, 0, 0);
+        for (int tn = 0; tn < TN; ++tn) {
+          if (PRECISE) {
+            if (ks == 0 && t == 0) {
+              const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              part[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][t], b[tn][t], zero, 0, 0, 0);
+            } else {
+              part[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][t], b[tn][t], part[tm][tn], 0, 0, 0);
+            }
+          } else {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][t], b[tn][t], acc[tm][tn], 0, 0, 0);
+          }
+        }
+  }
+  if (PRECISE) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] += part[tm][tn];
   }
 }
 
@@ -136,7 +158,7 @@ __device__ __forceinline__ void epilogue(const EpilogueArgs& ep, int m_base, int
 // ---------------------------------------------------------------------------------------------
 // Convolution
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PRECISE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int RA = BM / 32, RB = BN / 32;
@@ -210,7 +232,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
       *reinterpret_cast<f32x4*>(&Bs[(tr + 32 * j) * CF_LDS_STRIDE + ts * 4]) = rb[j];
     __syncthreads();
     if (c + 1 < p.n_chunks) load_chunk(c + 1);  // in flight while the MFMAs below run
-    mma_chunk<TM, TN>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+    mma_chunk<TM, TN, PRECISE>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
   }
   epilogue<TM, TN>(p.ep, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, acc);
 }
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 // ---------------------------------------------------------------------------------------------
 // DCNv2 (3x3, stride 1, pad 1): bilinear gather fused into the A-chunk staging
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PRECISE>
 __global__ __launch_bounds__(256) void dcn_igemm_kernel(DcnK p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int RA = BM / 32, RB = BN / 32;
@@ -296,7 +318,7 @@ __global__ __launch_bounds__(256) void dcn_igemm_kernel(DcnK p) {
     for (int j = 0; j < RB; ++j)
       *reinterpret_cast<f32x4*>(&Bs[(tr + 32 * j) * CF_LDS_STRIDE + ts * 4]) = rb[j];
     __syncthreads();
-    mma_chunk<TM, TN>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+    mma_chunk<TM, TN, PRECISE>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
   }
   epilogue<TM, TN>(p.ep, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, acc);
 }
@@ -321,7 +343,8 @@ TileCfg pick_tile(long M, int N_pad) {
   do {                                                                                  \
     const int MT = (int)((M + BM_ - 1) / BM_), NT = N_pad / BN_;                        \
     ARGS.NT = NT;                                                                       \
-    hipLaunchKernelGGL((KERNEL<BM_, BN_, WM_, WN_>), dim3(MT * NT), dim3(256), 0, st, ARGS); \
+    if (precise) hipLaunchKernelGGL((KERNEL<BM_, BN_, WM_, WN_, true>), dim3(MT * NT), dim3(256), 0, st, ARGS);   \
+    else hipLaunchKernelGGL((KERNEL<BM_, BN_, WM_, WN_, false>), dim3(MT * NT), dim3(256), 0, st, ARGS); \
   } while (0)
 
 #define DISPATCH_TILE(KERNEL, ARGS)                                        \
@@ -362,6 +385,7 @@ extern "C" int cf_conv2d_fused(const cf_conv_args* a, void* stream) {
   k.ep = EpilogueArgs{a->bias, a->residual, a->out, a->out2, a->res_stride, a->out_stride,
                       a->out_layout, a->act, (int)M, a->N, a->Ho * a->Wo};
   const int N_pad = a->N_pad;
+  const bool precise = a->precise != 0;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_TILE(conv_igemm_kernel, k);
   return cf_check_launch("cf_conv2d_fused");
@@ -385,6 +409,7 @@ extern "C" int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream) {
   k.ep = EpilogueArgs{a->bias, nullptr, a->out, nullptr, 0, a->out_stride, CF_LAYOUT_NHWC, a->act,
                       (int)M, a->N, a->H * a->W};
   const int N_pad = a->N_pad;
+  const bool precise = a->precise != 0;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_TILE(dcn_igemm_kernel, k);
   return cf_check_launch("cf_dcn_v2_fused");

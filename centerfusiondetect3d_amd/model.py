@@ -175,7 +175,10 @@ class _Plan:
             return t
 
         def conv(name, srcs, h, w, act=ACT_RELU, residual=None, out=None, out_stride=None,
-                 out_offset=0, layout=LAYOUT_NHWC, out2=None, strides=None):
+                 out_offset=0, layout=LAYOUT_NHWC, out2=None, strides=None, precise=None):
+            # everything that feeds the DCN neck sums in two levels (cf_gemm.hip: PRECISE); the
+            # heads come after it, their rounding is not amplified
+            precise = (model.precise and not name.startswith("heads.")) if precise is None else precise
             pc = pk[name]
             ho = (h + 2 * pc.pad - pc.kh) // pc.stride + 1
             wo = (w + 2 * pc.pad - pc.kh) // pc.stride + 1
@@ -184,7 +187,7 @@ class _Plan:
             a = ops.conv_args(pc, srcs, strides or [s.shape[-1] for s in srcs], B, h, w, out,
                               out_stride or pc.n, act, residual,
                               residual.shape[-1] if residual is not None else 0, layout, out2,
-                              out_offset)
+                              out_offset, precise)
             self.keep.append(a)
             self.step_index[name] = len(self.steps)
             self.step_flops[name] = 2.0 * B * ho * wo * pc.n * (pc.kh * pc.kh * sum(
@@ -231,7 +234,7 @@ class _Plan:
             conv(p + ".conv_offset_mask", [x], h, w, act=ACT_NONE, out=om, out_stride=32)
             pd = pk[p]
             o = buf(B, h, w, pd.n)
-            a = ops.dcn_args(pd, x, om, 32, B, h, w, o, pd.n, ACT_RELU)
+            a = ops.dcn_args(pd, x, om, 32, B, h, w, o, pd.n, ACT_RELU, precise=model.precise)
             self.keep.append(a)
             self.step_index[p] = len(self.steps)
             self.step_flops[p] = 2.0 * B * h * w * pd.n * 9 * pd.c
@@ -288,7 +291,7 @@ class _Plan:
                 ACT_RAW_AND_SIGDEPTH if h in ("depth", "depth2") else ACT_NONE)
             pc = pk[f"heads.{h}.out"]
             a = ops.conv_args(pc, [src], [src_stride], B, h4, w4, src, 0, act, None, 0,
-                              LAYOUT_NCHW, src if act == ACT_RAW_AND_SIGDEPTH else None)
+                              LAYOUT_NCHW, src if act == ACT_RAW_AND_SIGDEPTH else None, 0, False)
             self.keep.append(a)
             self.step_index[f"heads.{h}.out"] = len(self.steps)
             self.step_flops[f"heads.{h}.out"] = 2.0 * B * h4 * w4 * pc.n * 256
@@ -404,6 +407,7 @@ class DLASeg(nn.Module):
             _register(self, name, tensor, is_buf)
         self._packed = None
         self._plans = {}
+        self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
         self.eval()
 

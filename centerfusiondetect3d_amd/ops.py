@@ -23,7 +23,7 @@ def _need_cuda(*ts):
 
 def conv_args(pc: PackedConv, srcs: Sequence[torch.Tensor], src_strides: Sequence[int], B, H, W,
               out: torch.Tensor, out_stride: int, act=ACT_NONE, residual=None, res_stride=0,
-              layout=LAYOUT_NHWC, out2=None, out_offset=0) -> _lib.ConvArgs:
+              layout=LAYOUT_NHWC, out2=None, out_offset=0, precise=True) -> _lib.ConvArgs:
     """Build (and return for reuse) the argument block of one fused convolution."""
     a = _lib.ConvArgs()
     for i, (s, c) in enumerate(zip(srcs, src_strides)):
@@ -41,6 +41,7 @@ def conv_args(pc: PackedConv, srcs: Sequence[torch.Tensor], src_strides: Sequenc
     a.out = out.data_ptr() + 4 * out_offset
     a.out2 = _lib.ptr(out2)
     a.out_stride, a.out_layout, a.act = out_stride, layout, act
+    a.precise = int(bool(precise))
     return a
 
 
@@ -49,7 +50,7 @@ def run_conv(a: _lib.ConvArgs):
 
 
 def conv2d_fused(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, residual=None, layout=LAYOUT_NHWC,
-                 out=None, out2=None):
+                 out=None, out2=None, precise=True):
     """Convenience form: allocates the output.  srcs: NHWC tensors (B,H,W,Ci)."""
     _need_cuda(*srcs, residual)
     Ho = (H + 2 * pc.pad - pc.kh) // pc.stride + 1
@@ -61,17 +62,19 @@ def conv2d_fused(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, residual=None, lay
     if act == ACT_RAW_AND_SIGDEPTH and out2 is None:
         out2 = torch.empty_like(out)
     a = conv_args(pc, srcs, [s.shape[-1] for s in srcs], B, H, W, out, pc.n, act, residual,
-                  residual.shape[-1] if residual is not None else 0, layout, out2)
+                  residual.shape[-1] if residual is not None else 0, layout, out2, 0, precise)
     run_conv(a)
     return (out, out2) if act == ACT_RAW_AND_SIGDEPTH else out
 
 
-def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act=ACT_RELU):
+def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act=ACT_RELU,
+             precise=True):
     a = _lib.DcnArgs()
     a.x, a.offmask, a.om_stride = x.data_ptr(), offmask.data_ptr(), om_stride
     a.B, a.H, a.W, a.C = B, H, W, pd.c
     a.weight, a.bias, a.N, a.N_pad = pd.weight.data_ptr(), pd.bias.data_ptr(), pd.n, pd.n_pad
     a.out, a.out_stride, a.act = out.data_ptr(), out_stride, act
+    a.precise = int(bool(precise))
     return a
 
 
@@ -79,12 +82,12 @@ def run_dcn(a: _lib.DcnArgs):
     _lib.check(_lib.load().cf_dcn_v2_fused(C.byref(a), _lib.stream_ptr()), "cf_dcn_v2_fused")
 
 
-def dcn_v2_fused(pd: PackedDcn, x, offmask, act=ACT_RELU):
+def dcn_v2_fused(pd: PackedDcn, x, offmask, act=ACT_RELU, precise=True):
     """x (B,H,W,C) NHWC, offmask (B,H,W,S>=27) NHWC raw conv_offset_mask output."""
     _need_cuda(x, offmask)
     B, H, W, _ = x.shape
     out = torch.empty((B, H, W, pd.n), device=x.device, dtype=torch.float32)
-    run_dcn(dcn_args(pd, x, offmask, offmask.shape[-1], B, H, W, out, pd.n, act))
+    run_dcn(dcn_args(pd, x, offmask, offmask.shape[-1], B, H, W, out, pd.n, act, precise))
     return out
 
 

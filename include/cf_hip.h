@@ -75,6 +75,7 @@ typedef struct cf_conv_args {
   int32_t out_stride;           /* floats per pixel of the NHWC destination (>= N)                    */
   int32_t out_layout;           /* CF_LAYOUT_*                                                        */
   int32_t act;                  /* CF_ACT_*                                                           */
+  int32_t precise;              /* !=0: two-level (per-32-K-chunk) fp32 summation, see cf_gemm.hip    */
 } cf_conv_args;
 int cf_conv2d_fused(const cf_conv_args* a, void* stream);
 
@@ -95,6 +96,7 @@ typedef struct cf_dcn_args {
   float* out;           /* NHWC [B][H][W][out_stride]           */
   int32_t out_stride;
   int32_t act;
+  int32_t precise;      /* as cf_conv_args.precise              */
 } cf_dcn_args;
 int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream);
 

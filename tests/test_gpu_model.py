@@ -2,8 +2,8 @@
 vectors produced by the reference's own forward and (b) the CPU oracle, through the drop-in
 boundary `model(images, pc_dep=, calib=) -> [dict]`.
 
-Tolerance (north star "within 1e-3 relative fp32"): |got - ref| <= 1e-3*|ref| + 3e-4*max|ref| per
-element (so elements near zero are judged against the map's scale, three times tighter than the
+Tolerance (north star "within 1e-3 relative fp32"): |got - ref| <= 1e-3*|ref| + 2e-4*max|ref| per
+element (so elements near zero are judged against the map's scale, five times tighter than the
 normwise 1e-3); the index path (top-k, painted pixel set) must be identical.  The worst normwise
 error actually observed is printed (pytest -s) and quoted in DESIGN.md."""
 import os
@@ -18,7 +18,7 @@ from oracle import model_ref, decode_ref
 from tests.golden import cases
 
 RTOL = 1e-3
-ATOL_SCALE = 3e-4
+ATOL_SCALE = 2e-4
 
 
 @pytest.fixture(scope="module")
