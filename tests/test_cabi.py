@@ -1,0 +1,68 @@
+"""CPU: libcfhip.so loads, exports every symbol include/cf_hip.h declares, and the ctypes
+mirrors of the argument structs have the C compiler's layout.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "cf_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported_and_bound():
+    from centerfusiondetect3d_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in cf_hip.h but not exported by libcfhip.so"
+        assert n in _lib.SYMBOLS, f"{n} has no ctypes binding"
+    assert set(_lib.SYMBOLS) == set(names)
+    assert lib.cf_abi_version() == 1
+    assert lib.cf_topk_workspace_bytes(16) == 0
+
+
+def test_struct_layouts_match_c(tmp_path):
+    from centerfusiondetect3d_amd import _lib
+    prog = tmp_path / "sz.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cf_hip.h"\nint main(){'
+                    'printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(cf_conv_args), sizeof(cf_dcn_args),'
+                    'sizeof(cf_decode_args), sizeof(cf_slot), offsetof(cf_conv_args, weight),'
+                    'offsetof(cf_conv_args, precise), offsetof(cf_dcn_args, precise));return 0;}')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == [ctypes.sizeof(_lib.ConvArgs), ctypes.sizeof(_lib.DcnArgs), ctypes.sizeof(_lib.DecodeArgs),
+                   16, _lib.ConvArgs.weight.offset, _lib.ConvArgs.precise.offset, _lib.DcnArgs.precise.offset]
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device."""
+    from centerfusiondetect3d_amd import _lib
+    lib = _lib.load()
+    a = _lib.ConvArgs()
+    assert lib.cf_conv2d_fused(ctypes.byref(a), None) == -22
+    assert b"n_src" in lib.cf_last_error()
+    d = _lib.DcnArgs()
+    d.C = 48
+    assert lib.cf_dcn_v2_fused(ctypes.byref(d), None) == -22
+    assert b"multiple of 32" in lib.cf_last_error()
+    assert lib.cf_topk_peaks(None, 1, 1, 1, 1, 1, 0, None, None, None, None, None) == -22
+    assert lib.cf_upsample_dw(None, None, None, None, 1, 1, 1, 4, 2, None) == -22
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from centerfusiondetect3d_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libcfhip.so")
+    with pytest.raises(_lib.CfHipError, match="no CPU fallback"):
+        _lib.load()
