@@ -46,7 +46,7 @@ SYMBOLS = {
     "cf_maxpool2x2": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "cf_nchw_to_nhwc4": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "cf_nhwc_to_nchw": (_i, [_f, _f, _i, _i, _i, _i, _i, _f]),
-    "cf_topk_workspace_bytes": (C.c_size_t, [_i]),
+    "cf_topk_workspace_bytes": (C.c_size_t, [_i, _i]),
     "cf_topk_peaks": (_i, [_f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "cf_frustum_assoc": (_i, [_f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, C.c_float, _f, _f, _f]),
     "cf_pillar_expand": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _i, _i, _d, _d, _d, _f, _f, _f, _f]),

@@ -6,15 +6,18 @@
 // operation like the reference's fp32 / fp64 expressions, and this file is compiled with
 // -ffp-contract=off so no multiply-add is fused behind our back.
 //
-// One workgroup per image/frame: the per-image working set (10x112x200 scores = 896 KB, 3x112x200
+// One workgroup per image/frame (top-k: 16 slice workgroups + a merge): the per-image working set (10x112x200 scores = 896 KB, 3x112x200
 // radar map = 269 KB) is L2-resident after the first pass, and every ordering decision (top-K
 // order, "last painted box wins", "farthest radar point wins") is resolved inside LDS.
 #include "cf_common.h"
 
 namespace {
 
-constexpr int TOPK_THREADS = 1024;
-constexpr int TOPK_CAP = 4096;  // candidate keys kept in LDS (32 KiB)
+constexpr int TOPK_THREADS = 256;   // slice kernel
+constexpr int TOPK_MERGE_THREADS = 1024;
+constexpr int TOPK_CAP = 4096;      // candidate keys kept in LDS (32 KiB)
+constexpr int TOPK_SLICES = 16;     // workgroups per image in the slice pass
+constexpr int TOPK_MAXK = 256;      // K <= number of threads of the slice kernel
 
 __device__ __forceinline__ uint32_t f2u(float f) {  // order-preserving float -> uint
   const uint32_t u = __float_as_uint(f);
@@ -61,31 +64,45 @@ __device__ void bitonic_sort_desc(uint64_t* keys, int P) {
   }
 }
 
-// Top-K of one image, ordered by (score desc, flat index asc) == (score desc, class asc, pixel asc).
-//  A. every thread takes the max of its strided share -> the K-th largest of the 1024 local maxima
-//     is a lower bound L of the K-th largest element (at least K elements are >= L);
+// Pass 1: top-K of one SLICE of one image (TOPK_SLICES workgroups per image), as sorted 64-bit keys
+// (order-preserving score bits << 32 | ~flat_index), i.e. ordered by (score desc, flat index asc)
+// == (score desc, class asc, pixel asc).  Every element of the image's top-K is in its slice's
+// top-K, so pass 2 only has to merge TOPK_SLICES * K keys.
+//  A. every thread takes the max of its strided share -> the K-th largest of the 256 local maxima
+//     is a lower bound L of the slice's K-th largest element (at least K elements are >= L);
 //  B. elements > L are collected into LDS; if fewer than K, the missing ones are the elements == L
-//     with the smallest indices, taken by an index-ordered block scan (this is the common case on
-//     real heat maps: the clamp plateau at 1e-4 ties everywhere);
-//  C. the <= 4096 candidates are bitonic-sorted on (score, ~index) keys.
+//     with the smallest indices, taken by an index-ordered block scan (the common case on real heat
+//     maps: the clamp plateau at 1e-4 ties everywhere);
+//  C. the <= 4096 candidates are bitonic-sorted.
 // If more than 4096 elements exceed L (adversarial input), the exact K-th value is found by a
 // 4 x 8-bit radix select and step B is repeated with it.
 template <bool NMS>
-__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ heat, int C, int H,
-                                                            int W, int K, float* __restrict__ scores,
-                                                            int32_t* __restrict__ inds,
-                                                            int32_t* __restrict__ classes) {
+__global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* __restrict__ heat, int C, int H,
+                                                                  int W, int K, uint64_t* __restrict__ out_keys) {
   __shared__ uint64_t keys[TOPK_CAP];
   __shared__ uint32_t hist[256];
   __shared__ uint32_t wave_cnt[TOPK_THREADS / 64];
-  __shared__ uint32_t s_gt, s_sel[3];
+  __shared__ uint32_t s_gt, s_sel[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HW = H * W, N = C * HW;
-  const float* img = heat + (size_t)blockIdx.x * N;
+  const int img_i = blockIdx.x / TOPK_SLICES, slice = blockIdx.x % TOPK_SLICES;
+  const float* img = heat + (size_t)img_i * N;
+  const int len = (N + TOPK_SLICES - 1) / TOPK_SLICES;
+  const int lo = min(slice * len, N), hi = min(lo + len, N);
+  uint64_t* out = out_keys + (size_t)blockIdx.x * K;
+  const int n = hi - lo;
+  if (n <= K) {  // tiny slice: everything is a candidate
+    for (int i = tid; i < TOPK_MAXK; i += TOPK_THREADS)
+      keys[i] = i < n ? (((uint64_t)f2u(peak_value<NMS>(img, lo + i, H, W)) << 32) | (uint32_t)(~(uint32_t)(lo + i))) : 0ull;
+    __syncthreads();
+    bitonic_sort_desc(keys, TOPK_MAXK);
+    for (int j = tid; j < K; j += TOPK_THREADS) out[j] = keys[j];
+    return;
+  }
 
   // ---- A: lower bound from local maxima
   uint32_t lmax = 0;
-  for (int i = tid; i < N; i += TOPK_THREADS) lmax = max(lmax, f2u(peak_value<NMS>(img, i, H, W)));
+  for (int i = lo + tid; i < hi; i += TOPK_THREADS) lmax = max(lmax, f2u(peak_value<NMS>(img, i, H, W)));
   keys[tid] = lmax;
   __syncthreads();
   bitonic_sort_desc(keys, TOPK_THREADS);
@@ -96,7 +113,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (tid == 0) s_gt = 0;
     __syncthreads();
-    for (int i = tid; i < N; i += TOPK_THREADS) {
+    for (int i = lo + tid; i < hi; i += TOPK_THREADS) {
       const uint32_t u = f2u(peak_value<NMS>(img, i, H, W));
       if (u > L) {
         const uint32_t pos = atomicAdd(&s_gt, 1u);
@@ -111,7 +128,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
       const int shift = pass * 8;
       for (int i = tid; i < 256; i += TOPK_THREADS) hist[i] = 0;
       __syncthreads();
-      for (int i = tid; i < N; i += TOPK_THREADS) {
+      for (int i = lo + tid; i < hi; i += TOPK_THREADS) {
         const uint32_t u = f2u(peak_value<NMS>(img, i, H, W));
         if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
       }
@@ -140,9 +157,9 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
     // index-ordered selection of the (K - g) smallest-index elements equal to L
     const int r = K - g;
     int found = 0;
-    for (int base = 0; base < N && found < r; base += TOPK_THREADS) {
+    for (int base = lo; base < hi && found < r; base += TOPK_THREADS) {
       const int i = base + tid;
-      const bool eq = (i < N) && (f2u(peak_value<NMS>(img, i, H, W)) == L);
+      const bool eq = (i < hi) && (f2u(peak_value<NMS>(img, i, H, W)) == L);
       const unsigned long long bal = __ballot(eq);
       if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
       __syncthreads();
@@ -166,7 +183,23 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
   for (int i = total + tid; i < P; i += TOPK_THREADS) keys[i] = 0;
   __syncthreads();
   bitonic_sort_desc(keys, P);
-  for (int j = tid; j < K; j += TOPK_THREADS) {
+  for (int j = tid; j < K; j += TOPK_THREADS) out[j] = keys[j];
+}
+
+// Pass 2: merge the TOPK_SLICES sorted key lists of one image and emit scores / pixel / class.
+__global__ __launch_bounds__(TOPK_MERGE_THREADS) void topk_merge_kernel(const uint64_t* __restrict__ in_keys,
+                                                                        int K, int HW, float* __restrict__ scores,
+                                                                        int32_t* __restrict__ inds,
+                                                                        int32_t* __restrict__ classes) {
+  __shared__ uint64_t keys[TOPK_SLICES * TOPK_MAXK];
+  const int tid = threadIdx.x, total = TOPK_SLICES * K;
+  int P = 1;
+  while (P < total) P <<= 1;
+  const uint64_t* src = in_keys + (size_t)blockIdx.x * total;
+  for (int i = tid; i < P; i += TOPK_MERGE_THREADS) keys[i] = i < total ? src[i] : 0ull;
+  __syncthreads();
+  bitonic_sort_desc(keys, P);
+  for (int j = tid; j < K; j += TOPK_MERGE_THREADS) {
     const uint64_t key = keys[j];
     const uint32_t idx = ~(uint32_t)key;
     const int c = (int)(idx / (uint32_t)HW);
@@ -504,24 +537,24 @@ __global__ __launch_bounds__(PL_THREADS) void pillar_kernel(
 
 }  // namespace
 
-extern "C" size_t cf_topk_workspace_bytes(int B) {
-  (void)B;
-  return 0;  // the selection runs entirely in LDS
+extern "C" size_t cf_topk_workspace_bytes(int B, int K) {
+  return (size_t)(B > 0 ? B : 0) * TOPK_SLICES * (size_t)(K > 0 ? K : 0) * sizeof(uint64_t);
 }
 
 extern "C" int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
                              int32_t* inds, int32_t* classes, void* workspace, void* stream) {
-  (void)workspace;
-  CF_REQUIRE(heat && scores && inds && classes, "cf_topk_peaks: null buffer");
+  CF_REQUIRE(heat && scores && inds && classes && workspace, "cf_topk_peaks: null buffer");
   CF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cf_topk_peaks: bad geometry");
-  CF_REQUIRE(K >= 1 && K <= TOPK_THREADS, "cf_topk_peaks: K=%d outside [1,%d]", K, TOPK_THREADS);
+  CF_REQUIRE(K >= 1 && K <= TOPK_MAXK, "cf_topk_peaks: K=%d outside [1,%d]", K, TOPK_MAXK);
   CF_REQUIRE((long)C * H * W >= K, "cf_topk_peaks: fewer than K elements per image");
   CF_REQUIRE((long)C * H * W < (1L << 31), "cf_topk_peaks: image too large");
   hipStream_t st = (hipStream_t)stream;
+  uint64_t* keys = static_cast<uint64_t*>(workspace);
   if (nms)
-    hipLaunchKernelGGL(topk_kernel<true>, dim3(B), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, scores, inds, classes);
+    hipLaunchKernelGGL(topk_slice_kernel<true>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys);
   else
-    hipLaunchKernelGGL(topk_kernel<false>, dim3(B), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, scores, inds, classes);
+    hipLaunchKernelGGL(topk_slice_kernel<false>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys);
+  hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(TOPK_MERGE_THREADS), 0, st, keys, K, H * W, scores, inds, classes);
   return cf_check_launch("cf_topk_peaks");
 }
 

@@ -307,6 +307,7 @@ class _Plan:
             self.tk_inds = buf(B, K, dtype=torch.int32)
             self.tk_cls = buf(B, K, dtype=torch.int32)
             self.pc_hm4 = buf(B, h4, w4, 4)
+            self.tk_ws = buf(max(1, self.lib.cf_topk_workspace_bytes(B, K)), dtype=torch.uint8)
             self.topk_step = len(self.steps); self.steps.append(None)
             self.frustum_step = len(self.steps); self.steps.append(None)
             s1, _ = conv("heads.secondary.0", [feat, self.pc_hm4], h4, w4)     # (B,h4,w4,1024)
@@ -340,7 +341,8 @@ class _Plan:
             pc_hm = new(3)
             self.steps[self.topk_step] = (lib.cf_topk_peaks, y["heatmap"].data_ptr(), B, heads["heatmap"],
                                           h4, w4, self.K, 0, self.tk_scores.data_ptr(),
-                                          self.tk_inds.data_ptr(), self.tk_cls.data_ptr(), None)
+                                          self.tk_inds.data_ptr(), self.tk_cls.data_ptr(),
+                                          self.tk_ws.data_ptr())
             self.steps[self.frustum_step] = (
                 lib.cf_frustum_assoc, self.tk_inds.data_ptr(), self.K, y["depth"].data_ptr(),
                 y["widthHeight"].data_ptr(), y["dimension"].data_ptr(), y["rotation"].data_ptr(),

@@ -143,9 +143,11 @@ def topk_peaks(heat, K=100, nms=False):
     scores = torch.empty((B, K), device=dev, dtype=torch.float32)
     inds = torch.empty((B, K), device=dev, dtype=torch.int32)
     classes = torch.empty((B, K), device=dev, dtype=torch.int32)
-    _lib.check(_lib.load().cf_topk_peaks(heat.data_ptr(), B, Cc, H, W, K, int(bool(nms)),
-                                         scores.data_ptr(), inds.data_ptr(), classes.data_ptr(),
-                                         None, _lib.stream_ptr()), "cf_topk_peaks")
+    lib = _lib.load()
+    ws = torch.empty(max(1, lib.cf_topk_workspace_bytes(B, K)), device=dev, dtype=torch.uint8)
+    _lib.check(lib.cf_topk_peaks(heat.data_ptr(), B, Cc, H, W, K, int(bool(nms)),
+                                 scores.data_ptr(), inds.data_ptr(), classes.data_ptr(),
+                                 ws.data_ptr(), _lib.stream_ptr()), "cf_topk_peaks")
     return scores, inds, classes
 
 

@@ -121,8 +121,8 @@ int cf_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, int C, int 
  * equality NMS, ordered by (score desc, class asc, pixel asc).
  * replaces model/utils.py:6-38 (topk) [+ model/utils.py:112-128 (nms) when nms != 0].
  * outputs: scores (B,K) f32, inds (B,K) i32 pixel index in [0,H*W), classes (B,K) i32.
- * workspace: cf_topk_workspace_bytes(B) bytes. */
-size_t cf_topk_workspace_bytes(int B);
+ * workspace: cf_topk_workspace_bytes(B, K) bytes of device memory (per-slice candidate keys). */
+size_t cf_topk_workspace_bytes(int B, int K);
 int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
                   int32_t* inds, int32_t* classes, void* workspace, void* stream);
 

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported_and_bound():
         assert n in _lib.SYMBOLS, f"{n} has no ctypes binding"
     assert set(_lib.SYMBOLS) == set(names)
     assert lib.cf_abi_version() == 1
-    assert lib.cf_topk_workspace_bytes(16) == 0
+    assert lib.cf_topk_workspace_bytes(16, 100) == 16 * 16 * 100 * 8
 
 
 def test_struct_layouts_match_c(tmp_path):
