@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_PKG, "libcfhip.so")
 
 CF_MAX_SRC = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, ACT_RAW_AND_SIGDEPTH = 0, 1, 2, 3
-LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
+LAYOUT_NHWC, LAYOUT_NCHW, LAYOUT_NHWC_SPLIT_BF16 = 0, 1, 2
 
 _f = C.c_void_p  # device pointers travel as integers
 
@@ -41,6 +41,8 @@ class DecodeArgs(C.Structure):
 _i, _d = C.c_int, C.c_double
 SYMBOLS = {
     "cf_conv2d_fused": (_i, [C.POINTER(ConvArgs), _f]),
+    "cf_conv2d_bf16x3": (_i, [C.POINTER(ConvArgs), _f]),
+    "cf_split_bf16": (_i, [_f, _f, C.c_long, _i, _i, _i, _f]),
     "cf_dcn_v2_fused": (_i, [C.POINTER(DcnArgs), _f]),
     "cf_upsample_dw": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "cf_maxpool2x2": (_i, [_f, _f, _i, _i, _i, _i, _f]),
@@ -48,7 +50,7 @@ SYMBOLS = {
     "cf_nhwc_to_nchw": (_i, [_f, _f, _i, _i, _i, _i, _i, _f]),
     "cf_topk_workspace_bytes": (C.c_size_t, [_i, _i]),
     "cf_topk_peaks": (_i, [_f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
-    "cf_frustum_assoc": (_i, [_f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, C.c_float, _f, _f, _f]),
+    "cf_frustum_assoc": (_i, [_f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, C.c_float, _f, _f, _f, _f]),
     "cf_pillar_expand": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _i, _i, _d, _d, _d, _f, _f, _f, _f]),
     "cf_decode_gather": (_i, [C.POINTER(DecodeArgs), _f]),
     "cf_last_error": (C.c_char_p, []),

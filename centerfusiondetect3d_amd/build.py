@@ -21,6 +21,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"
 # (source, extra flags).  cf_post: the index path must not fuse mul+add (bit-exact slice bounds).
 SOURCES = [
     ("cf_gemm.hip", []),
+    ("cf_gemm_bf16.hip", []),
     ("cf_elementwise.hip", []),
     ("cf_post.hip", ["-ffp-contract=off"]),
     ("cf_error.cpp", []),

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
     const int32_t* __restrict__ inds, int K, const float* __restrict__ depth, const float* __restrict__ wh,
     const float* __restrict__ dim, const float* __restrict__ rot, const float* __restrict__ calib,
     const float* __restrict__ pc_dep, int H, int W, float max_pc_dist, float* __restrict__ pc_hm,
-    float* __restrict__ pc_hm_nhwc4) {
+    float* __restrict__ pc_hm_nhwc4, unsigned* __restrict__ pc_hm_split8) {
   __shared__ FrBox box[FR_MAXK];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HW = H * W;
@@ -361,6 +361,16 @@ __global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
     if (pc_hm_nhwc4) {
       const f32x4 o = {v0, v1, v2, 0.0f};
       reinterpret_cast<f32x4*>(pc_hm_nhwc4)[(size_t)b * HW + p] = o;
+    }
+    if (pc_hm_split8) {  // [pixel][hi 8][lo 8] bf16, channels 3..7 zero
+      const float h0 = (float)(__bf16)v0, h1 = (float)(__bf16)v1, h2 = (float)(__bf16)v2;
+      auto pk = [](float a, float bq) {
+        return ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)bq) << 16) |
+               __builtin_bit_cast(unsigned short, (__bf16)a);
+      };
+      unsigned* o = pc_hm_split8 + ((size_t)b * HW + p) * 8;
+      o[0] = pk(h0, h1); o[1] = pk(h2, 0.0f); o[2] = 0u; o[3] = 0u;
+      o[4] = pk(v0 - h0, v1 - h1); o[5] = pk(v2 - h2, 0.0f); o[6] = 0u; o[7] = 0u;
     }
   }
 }
@@ -561,12 +571,13 @@ extern "C" int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int 
 extern "C" int cf_frustum_assoc(const int32_t* inds, int K, const float* depth, const float* wh,
                                 const float* dim, const float* rot, const float* calib, const float* pc_dep,
                                 int B, int H, int W, float max_pc_dist, float* pc_hm, float* pc_hm_nhwc4,
-                                void* stream) {
+                                void* pc_hm_split8, void* stream) {
   CF_REQUIRE(inds && depth && wh && dim && rot && calib && pc_dep && pc_hm, "cf_frustum_assoc: null buffer");
   CF_REQUIRE(K >= 1 && K <= FR_MAXK, "cf_frustum_assoc: K=%d outside [1,%d]", K, FR_MAXK);
   CF_REQUIRE(B > 0 && H > 0 && W > 0, "cf_frustum_assoc: bad geometry");
   hipLaunchKernelGGL(frustum_kernel, dim3(B), dim3(FR_THREADS), 0, (hipStream_t)stream, inds, K, depth, wh, dim,
-                     rot, calib, pc_dep, H, W, max_pc_dist, pc_hm, pc_hm_nhwc4);
+                     rot, calib, pc_dep, H, W, max_pc_dist, pc_hm, pc_hm_nhwc4,
+                     static_cast<unsigned*>(pc_hm_split8));
   return cf_check_launch("cf_frustum_assoc");
 }
 

@@ -23,7 +23,7 @@ from torch import nn
 
 from . import _lib, ops, packing
 from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, ACT_RAW_AND_SIGDEPTH, LAYOUT_NHWC,
-                   LAYOUT_NCHW)
+                   LAYOUT_NCHW, LAYOUT_NHWC_SPLIT_BF16)
 from .packing import Source
 
 SECONDARY_HEADS = ["velocity", "nuscenes_att", "depth2", "rotation2"]   # detectHeads.py:146-153
@@ -280,11 +280,28 @@ class _Plan:
         self.h4, self.w4 = h4, w4
 
         # ---- heads.  Per-call output tensors are patched into these arg blocks (self.outs).
-        self.outs: Dict[str, List] = {}                    # head -> [(argblock, field)]
+        self.outs: Dict[str, List] = {}                    # head -> argblock
         primary = [h for h in heads if not (radar and h in SECONDARY_HEADS)]
         self.primary = primary
-        hid, _ = conv("heads.primary.0", [feat], h4, w4)   # (B,h4,w4,256*len(primary))
-        hs = hid.shape[-1]
+        self.radar = radar
+        self.K = K
+        bf = bool(model.heads_bf16)                        # split-bf16 ("bf16x3") head GEMMs
+        M4 = B * h4 * w4
+
+        def hconv(name, srcs, strides, out_c=None, out=None, out_offset=0, act=ACT_RELU):
+            """One hidden head layer: fp32 NHWC or split-bf16 NHWC, depending on model.heads_bf16."""
+            pc = pk[name]
+            if out is None:
+                out = buf(B, h4, w4, 2, out_c, dtype=torch.bfloat16) if bf else buf(B, h4, w4, out_c)
+            stride = out.shape[-1]
+            a = ops.conv_args(pc, srcs, strides, B, h4, w4, out, stride, act, None, 0,
+                              LAYOUT_NHWC_SPLIT_BF16 if bf else LAYOUT_NHWC, None, out_offset, False,
+                              2 if bf else 4)
+            self.keep.append(a)
+            self.step_index[name] = len(self.steps)
+            self.step_flops[name] = 2.0 * M4 * pc.n * (pc.kh * pc.kh * sum(int(c) for c in pc.real_cin))
+            self.steps.append((self.lib.cf_conv2d_bf16x3 if bf else self.lib.cf_conv2d_fused, C.byref(a)))
+            return out
 
         def head_out(h, src, src_stride):
             act = ACT_SIGMOID_CLAMP if h == "heatmap" else (
@@ -294,28 +311,35 @@ class _Plan:
                               LAYOUT_NCHW, src if act == ACT_RAW_AND_SIGDEPTH else None, 0, False)
             self.keep.append(a)
             self.step_index[f"heads.{h}.out"] = len(self.steps)
-            self.step_flops[f"heads.{h}.out"] = 2.0 * B * h4 * w4 * pc.n * 256
-            self.steps.append((self.lib.cf_conv2d_fused, C.byref(a)))
+            self.step_flops[f"heads.{h}.out"] = 2.0 * M4 * pc.n * 256
+            self.steps.append((self.lib.cf_conv2d_bf16x3 if bf else self.lib.cf_conv2d_fused, C.byref(a)))
             self.outs[h] = a
 
+        if bf:
+            feat_in = buf(B, h4, w4, 2, 64, dtype=torch.bfloat16)
+            self.steps.append((self.lib.cf_split_bf16, feat.data_ptr(), feat_in.data_ptr(), M4, 64, 64, 64))
+        else:
+            feat_in = feat
+        hs = 256 * len(primary)
+        hid = hconv("heads.primary.0", [feat_in], [64], out_c=hs)
         for h in primary:
             head_out(h, hid, hs)
-        self.radar = radar
-        self.K = K
         if radar:
             self.tk_scores = buf(B, K)
             self.tk_inds = buf(B, K, dtype=torch.int32)
             self.tk_cls = buf(B, K, dtype=torch.int32)
-            self.pc_hm4 = buf(B, h4, w4, 4)
+            self.pc_hm4 = None if bf else buf(B, h4, w4, 4)
+            self.pc_hm8 = buf(B, h4, w4, 2, 8, dtype=torch.bfloat16) if bf else None
             self.tk_ws = buf(max(1, self.lib.cf_topk_workspace_bytes(B, K)), dtype=torch.uint8)
             self.topk_step = len(self.steps); self.steps.append(None)
             self.frustum_step = len(self.steps); self.steps.append(None)
-            s1, _ = conv("heads.secondary.0", [feat, self.pc_hm4], h4, w4)     # (B,h4,w4,1024)
-            ss = s1.shape[-1]
-            s2 = buf(B, h4, w4, ss)
+            ss = 256 * len(SECONDARY_HEADS)
+            s1 = hconv("heads.secondary.0", [feat_in, self.pc_hm8 if bf else self.pc_hm4],
+                       [64, 8 if bf else 4], out_c=ss)
+            s2 = buf(B, h4, w4, 2, ss, dtype=torch.bfloat16) if bf else buf(B, h4, w4, ss)
             for n, h in enumerate(SECONDARY_HEADS):
-                conv(f"heads.{h}.2", [s1], h4, w4, out=s2, out_stride=ss, out_offset=256 * n, strides=[ss])
-                conv(f"heads.{h}.4", [s2], h4, w4, out=s1, out_stride=ss, out_offset=256 * n, strides=[ss])
+                hconv(f"heads.{h}.2", [s1], [ss], out=s2, out_offset=256 * n)
+                hconv(f"heads.{h}.4", [s2], [ss], out=s1, out_offset=256 * n)
                 head_out(h, s1, ss)
 
     # ------------------------------------------------------------------------------------------
@@ -348,7 +372,7 @@ class _Plan:
                 y["widthHeight"].data_ptr(), y["dimension"].data_ptr(), y["rotation"].data_ptr(),
                 calib.data_ptr(), pc_dep.data_ptr(), B, h4, w4,
                 C.c_float(float(model.config.DATASET.MAX_PC_DIST)), pc_hm.data_ptr(),
-                self.pc_hm4.data_ptr())
+                _lib.ptr(self.pc_hm4), _lib.ptr(self.pc_hm8))
             y["pc_hm_in"] = pc_dep[:, :1]
             y["pc_hm"] = pc_hm[:, 0, :, :].unsqueeze(1)
             for h in SECONDARY_HEADS:
@@ -410,6 +434,7 @@ class DLASeg(nn.Module):
         self._packed = None
         self._plans = {}
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
+        self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
         self.eval()
 
@@ -484,28 +509,27 @@ class DLASeg(nn.Module):
         for h in heads:
             if any(c != 256 for c in head_conv[h]):
                 raise NotImplementedError("head_conv widths other than 256 are not on the path")
-        w = torch.cat([sd[f"{hp}.{h}.0.weight"].float().cpu() for h in primary], 0)
-        b = torch.cat([sd[f"{hp}.{h}.0.bias"].float().cpu() for h in primary], 0)
-        pk["heads.primary.0"] = packing.pack_conv(w, b, [Source(64, 64)]).to(device)
+        bf = bool(self.heads_bf16)
+        pack = packing.pack_conv_bf16 if bf else packing.pack_conv
+        feat_src = Source(64, 64)
+        pc_src = Source(3, 8 if bf else 4)
+        hw = lambda h, i: sd[f"{hp}.{h}.{i}.weight"].float().cpu()
+        hb = lambda h, i: sd[f"{hp}.{h}.{i}.bias"].float().cpu()
+        pk["heads.primary.0"] = pack(torch.cat([hw(h, 0) for h in primary], 0),
+                                     torch.cat([hb(h, 0) for h in primary], 0), [feat_src]).to(device)
         for n, h in enumerate(primary):
             assert len(head_conv[h]) == 1
-            pk[f"heads.{h}.out"] = packing.pack_conv(
-                sd[f"{hp}.{h}.2.weight"].float().cpu(), sd[f"{hp}.{h}.2.bias"].float().cpu(),
-                [Source(256, 256 * len(primary), 256 * n)]).to(device)
+            pk[f"heads.{h}.out"] = pack(hw(h, 2), hb(h, 2), [Source(256, 256 * len(primary), 256 * n)]).to(device)
         if radar:
-            w = torch.cat([sd[f"{hp}.{h}.0.weight"].float().cpu() for h in SECONDARY_HEADS], 0)
-            b = torch.cat([sd[f"{hp}.{h}.0.bias"].float().cpu() for h in SECONDARY_HEADS], 0)
-            pk["heads.secondary.0"] = packing.pack_conv(w, b, [Source(64, 64), Source(3, 4)]).to(device)
+            pk["heads.secondary.0"] = pack(torch.cat([hw(h, 0) for h in SECONDARY_HEADS], 0),
+                                           torch.cat([hb(h, 0) for h in SECONDARY_HEADS], 0),
+                                           [feat_src, pc_src]).to(device)
             ns = 256 * len(SECONDARY_HEADS)
             for n, h in enumerate(SECONDARY_HEADS):
                 assert len(head_conv[h]) == 3
                 for idx in (2, 4):
-                    pk[f"heads.{h}.{idx}"] = packing.pack_conv(
-                        sd[f"{hp}.{h}.{idx}.weight"].float().cpu(), sd[f"{hp}.{h}.{idx}.bias"].float().cpu(),
-                        [Source(256, ns, 256 * n)]).to(device)
-                pk[f"heads.{h}.out"] = packing.pack_conv(
-                    sd[f"{hp}.{h}.6.weight"].float().cpu(), sd[f"{hp}.{h}.6.bias"].float().cpu(),
-                    [Source(256, ns, 256 * n)]).to(device)
+                    pk[f"heads.{h}.{idx}"] = pack(hw(h, idx), hb(h, idx), [Source(256, ns, 256 * n)]).to(device)
+                pk[f"heads.{h}.out"] = pack(hw(h, 6), hb(h, 6), [Source(256, ns, 256 * n)]).to(device)
         self._packed = pk
 
     # ----------------------------------------------------------------------------------- forward

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, ACT_RAW_AND_SIGDEPTH, LAYOUT_NHWC,
-                   LAYOUT_NCHW)
+                   LAYOUT_NCHW, LAYOUT_NHWC_SPLIT_BF16)
 from .packing import PackedConv, PackedDcn
 
 
@@ -23,7 +23,7 @@ def _need_cuda(*ts):
 
 def conv_args(pc: PackedConv, srcs: Sequence[torch.Tensor], src_strides: Sequence[int], B, H, W,
               out: torch.Tensor, out_stride: int, act=ACT_NONE, residual=None, res_stride=0,
-              layout=LAYOUT_NHWC, out2=None, out_offset=0, precise=True) -> _lib.ConvArgs:
+              layout=LAYOUT_NHWC, out2=None, out_offset=0, precise=True, elem_bytes=4) -> _lib.ConvArgs:
     """Build (and return for reuse) the argument block of one fused convolution."""
     a = _lib.ConvArgs()
     for i, (s, c) in enumerate(zip(srcs, src_strides)):
@@ -38,7 +38,7 @@ def conv_args(pc: PackedConv, srcs: Sequence[torch.Tensor], src_strides: Sequenc
     a.K_pad, a.N, a.N_pad = pc.k_pad, pc.n, pc.n_pad
     a.residual = _lib.ptr(residual)
     a.res_stride = res_stride
-    a.out = out.data_ptr() + 4 * out_offset
+    a.out = out.data_ptr() + elem_bytes * out_offset
     a.out2 = _lib.ptr(out2)
     a.out_stride, a.out_layout, a.act = out_stride, layout, act
     a.precise = int(bool(precise))
@@ -64,6 +64,43 @@ def conv2d_fused(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, residual=None, lay
     a = conv_args(pc, srcs, [s.shape[-1] for s in srcs], B, H, W, out, pc.n, act, residual,
                   residual.shape[-1] if residual is not None else 0, layout, out2, 0, precise)
     run_conv(a)
+    return (out, out2) if act == ACT_RAW_AND_SIGDEPTH else out
+
+
+def run_conv_bf16(a: _lib.ConvArgs):
+    _lib.check(_lib.load().cf_conv2d_bf16x3(C.byref(a), _lib.stream_ptr()), "cf_conv2d_bf16x3")
+
+
+def split_bf16(x, channels=None, cs=None, out=None):
+    """fp32 NHWC (B,H,W,S) -> split-bf16 (B,H,W,2,Cs) stored as a bf16 tensor."""
+    _need_cuda(x)
+    B, H, W, S = x.shape
+    Cc = channels or S
+    Cs = cs or ((Cc + 7) // 8) * 8
+    if out is None:
+        out = torch.empty((B, H, W, 2, Cs), device=x.device, dtype=torch.bfloat16)
+    _lib.check(_lib.load().cf_split_bf16(x.data_ptr(), out.data_ptr(), B * H * W, Cc, S, Cs,
+                                         _lib.stream_ptr()), "cf_split_bf16")
+    return out
+
+
+def conv2d_bf16x3(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, layout=LAYOUT_NHWC_SPLIT_BF16,
+                  out=None, out2=None):
+    """srcs: split-bf16 tensors (B,H,W,2,Cs).  Returns split-bf16 (B,Ho,Wo,2,N) or fp32 NCHW."""
+    _need_cuda(*srcs)
+    Ho = (H + 2 * pc.pad - pc.kh) // pc.stride + 1
+    Wo = (W + 2 * pc.pad - pc.kh) // pc.stride + 1
+    dev = srcs[0].device
+    if out is None:
+        if layout == LAYOUT_NHWC_SPLIT_BF16:
+            out = torch.empty((B, Ho, Wo, 2, pc.n), device=dev, dtype=torch.bfloat16)
+        else:
+            out = torch.empty((B, pc.n, Ho, Wo), device=dev, dtype=torch.float32)
+    if act == ACT_RAW_AND_SIGDEPTH and out2 is None:
+        out2 = torch.empty_like(out)
+    a = conv_args(pc, srcs, [s.shape[-1] for s in srcs], B, H, W, out, pc.n, act, None, 0, layout,
+                  out2, 0, False)
+    run_conv_bf16(a)
     return (out, out2) if act == ACT_RAW_AND_SIGDEPTH else out
 
 
@@ -152,7 +189,7 @@ def topk_peaks(heat, K=100, nms=False):
 
 
 def frustum_assoc(inds, depth, wh, dim, rot, calib, pc_dep, max_pc_dist=60.0, want_nhwc4=False,
-                  pc_hm=None, pc_hm_nhwc4=None):
+                  pc_hm=None, pc_hm_nhwc4=None, pc_hm_split8=None):
     _need_cuda(inds, depth, wh, dim, rot, calib, pc_dep)
     B, _, H, W = pc_dep.shape
     K = inds.shape[1]
@@ -164,7 +201,8 @@ def frustum_assoc(inds, depth, wh, dim, rot, calib, pc_dep, max_pc_dist=60.0, wa
     ts = [t if t.is_contiguous() else t.contiguous() for t in (depth, wh, dim, rot, calib, pc_dep)]
     _lib.check(_lib.load().cf_frustum_assoc(inds.data_ptr(), K, *(t.data_ptr() for t in ts), B, H,
                                             W, float(max_pc_dist), pc_hm.data_ptr(),
-                                            _lib.ptr(pc_hm_nhwc4), _lib.stream_ptr()),
+                                            _lib.ptr(pc_hm_nhwc4), _lib.ptr(pc_hm_split8),
+                                            _lib.stream_ptr()),
                "cf_frustum_assoc")
     return (pc_hm, pc_hm_nhwc4) if want_nhwc4 else pc_hm
 

@@ -94,6 +94,44 @@ def pack_conv(weight, bias, sources: Sequence[Source], stride=1, pad=None, dilat
                       tuple(s.channels for s in sources))
 
 
+def pack_conv_bf16(weight, bias, sources: Sequence[Source], stride=1, pad=None, dilation=1) -> PackedConv:
+    """Packing for cf_conv2d_bf16x3: slots of 8 channels, weights [N_pad][2][K_pad] bf16 with
+    w = hi + lo (hi = rne(w), lo = rne(w - hi)).  Source.stride = channels per plane."""
+    co, ci, kh, kw = weight.shape
+    assert ci == sum(s.channels for s in sources), (ci, [s.channels for s in sources])
+    pad = (kh - 1) // 2 * dilation if pad is None else pad
+    n_pad = ((co + 31) // 32) * 32
+    slots, cols, c_lo = [], [], 0
+    for si, s in enumerate(sources):
+        assert s.stride % 8 == 0 and s.c_base % 8 == 0
+        per_tap = (s.channels + 7) // 8
+        n_slots = 0
+        for r in range(kh):
+            for q in range(kw):
+                for g in range(per_tap):
+                    real = min(8, s.channels - 8 * g)
+                    slots.append([si, r * dilation - pad, q * dilation - pad, s.c_base + 8 * g])
+                    cols.append((c_lo + 8 * g, real, r, q))
+                    n_slots += 1
+        while n_slots % 4:                 # a 32-wide chunk = 4 slots, one source per chunk
+            slots.append([si, 0, 0, -1])
+            cols.append((-1, 0, 0, 0))
+            n_slots += 1
+        c_lo += s.channels
+    k_pad = len(slots) * 8
+    w = torch.zeros(n_pad, k_pad)
+    wf = weight.float()
+    for j, (c0, real, r, q) in enumerate(cols):
+        if real:
+            w[:co, 8 * j:8 * j + real] = wf[:, c0:c0 + real, r, q]
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    b = torch.zeros(n_pad)
+    b[:co] = bias
+    return PackedConv(torch.stack([hi, lo], dim=1).contiguous(), b, torch.tensor(slots, dtype=torch.int32),
+                      co, n_pad, k_pad, kh, stride, pad, tuple(s.channels for s in sources))
+
+
 @dataclass
 class PackedDcn:
     weight: torch.Tensor   # [N_pad, 9*C]  k = tap*C + c

@@ -37,6 +37,7 @@ extern "C" {
 
 #define CF_LAYOUT_NHWC 0
 #define CF_LAYOUT_NCHW 1
+#define CF_LAYOUT_NHWC_SPLIT_BF16 2 /* per pixel [C hi][C lo] bf16, x = hi + lo (cf_conv2d_bf16x3) */
 
 /* One 16-byte K-slot of the implicit GEMM: 4 consecutive channels of one source at one tap. */
 typedef struct cf_slot {
@@ -78,6 +79,19 @@ typedef struct cf_conv_args {
   int32_t precise;              /* !=0: two-level (per-32-K-chunk) fp32 summation, see cf_gemm.hip    */
 } cf_conv_args;
 int cf_conv2d_fused(const cf_conv_args* a, void* stream);
+
+/* cf_conv2d_bf16x3: the same implicit GEMM on the bf16 MFMA pipe with split operands
+ * (x = hi + lo, both bf16; a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate; <= ~2^-17
+ * relative error per product at 5.3x the fp32-MFMA rate).  Used for the head convolutions
+ * (model/networks/detectHeads.py:59-98, 165-191), which are not followed by the error-amplifying
+ * DCN neck.  Same argument block as cf_conv2d_fused, read as follows: src[] are split-bf16 NHWC
+ * tensors (src_c = channels per plane, multiple of 8); one slot = 8 channels; weight is
+ * [N_pad][2][K_pad] bf16 (hi plane, lo plane); out is either CF_LAYOUT_NHWC_SPLIT_BF16
+ * (out_stride = channels per plane) or CF_LAYOUT_NCHW fp32; residual / precise are ignored. */
+int cf_conv2d_bf16x3(const cf_conv_args* a, void* stream);
+
+/* cf_split_bf16: fp32 NHWC [M][in_stride] (C used) -> split-bf16 [M][2][Cs], channels C..Cs-1 zero. */
+int cf_split_bf16(const float* x, void* out, long M, int C, int in_stride, int Cs, void* stream);
 
 /* cf_dcn_v2_fused: modulated deformable 3x3 convolution (stride 1, pad 1, dil 1, groups 1) with
  * the bilinear gather fused into the GEMM A-tile staging, + bias(BN folded) + ReLU.
@@ -130,12 +144,12 @@ int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms,
  * replaces utils/pointcloud.py:331-394 (getPcFrustumHeatmap, after its topk) and 397-481
  * (cvtPcDepthToHeatmap) incl. get_alpha / cvtAlphaToYaw / get3DCorners / getDistanceThresh
  * (pointcloud.py:195-328).  All maps NCHW fp32.  pc_hm (B,3,H,W) is fully written (zero where
- * nothing is painted); pc_hm_nhwc4 (B,H,W,4), if not NULL, receives the same data channels-last
- * for the secondary-head convolution. */
+ * nothing is painted); pc_hm_nhwc4 (B,H,W,4) fp32 and pc_hm_split8 (B,H,W,2,8) split-bf16, if not
+ * NULL, receive the same data channels-last for the secondary-head convolution. */
 int cf_frustum_assoc(const int32_t* inds, int K, const float* depth, const float* wh,
                      const float* dim, const float* rot, const float* calib, const float* pc_dep,
                      int B, int H, int W, float max_pc_dist, float* pc_hm, float* pc_hm_nhwc4,
-                     void* stream);
+                     void* pc_hm_split8, void* stream);
 
 /* cf_pillar_expand: radar points -> pc_dep (B,3,H,W) by pillar expansion (fp64 geometry).
  * replaces dataset/generic_dataset.py:738-942 (processPointCloud / transformPointCloud /

@@ -300,3 +300,67 @@ def test_pillar_expand_bit_exact_vs_oracle(dev, out_hw, img_wh):
         assert kb.sum() == tp.shape[1]
         assert np.array_equal(xy[b, :, :n].cpu().numpy()[:, kb], tp[:2])
         assert not keep[b, n:].any()
+
+
+# ------------------------------------------------------------------------------- bf16x3 (heads)
+def _split(x_nchw, dev, cs=None):
+    from centerfusiondetect3d_amd import ops
+    return ops.split_bf16(nhwc(x_nchw).to(dev), cs=cs)
+
+
+def _unsplit(t):
+    """(B,H,W,2,C) bf16 -> fp32 NCHW  (hi + lo)."""
+    f = t.float()
+    return (f[..., 0, :] + f[..., 1, :]).permute(0, 3, 1, 2).contiguous()
+
+
+def test_split_bf16_roundtrip(dev):
+    x = rnd(2, 67, 9, 11, seed=1) * 7
+    s = _split(x, dev, cs=72)
+    assert s.shape == (2, 9, 11, 2, 72) and s.dtype == torch.bfloat16
+    back = _unsplit(s).cpu()
+    assert float(back[:, 67:].abs().max()) == 0.0
+    rel = ((back[:, :67] - x).abs() / x.abs().clamp_min(1e-20)).max()
+    assert float(rel) < 2 ** -16                     # hi + lo carries 16 significant bits
+    hi = s[..., 0, :67].float().permute(0, 3, 1, 2).cpu()
+    assert torch.equal(hi, x.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("B,srcs,Co,H,W,k,act", [
+    (2, [(64, 64)], 256, 28, 50, 3, 1),                   # head first layer
+    (1, [(64, 64), (3, 8)], 128, 23, 31, 3, 1),           # feat || pc_hm, ragged M
+    (2, [(256, 256)], 256, 16, 24, 1, 1),                 # hidden 1x1
+])
+def test_conv2d_bf16x3_split_output(dev, B, srcs, Co, H, W, k, act):
+    from centerfusiondetect3d_amd import ops, packing
+    xs = [rnd(B, c, H, W, seed=10 + i) for i, (c, _) in enumerate(srcs)]
+    ci = sum(c for c, _ in srcs)
+    w, b = rnd(Co, ci, k, k, seed=2, scale=(ci * k * k) ** -0.5), rnd(Co, seed=3)
+    ref = F.conv2d(torch.cat(xs, 1), w, b, 1, k // 2)
+    if act:
+        ref = F.relu(ref)
+    pc = packing.pack_conv_bf16(w, b, [packing.Source(c, s) for c, s in srcs]).to(dev)
+    out = ops.conv2d_bf16x3(pc, [_split(x, dev, cs=s) for x, (_, s) in zip(xs, srcs)], B, H, W, act=act)
+    assert out.shape == (B, H, W, 2, Co)
+    got = _unsplit(out).cpu()
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 3e-5 * scale, float((got - ref).abs().max()) / scale
+
+
+def test_conv2d_bf16x3_nchw_outputs_and_slices(dev):
+    from centerfusiondetect3d_amd import ops, packing
+    B, H, W = 2, 9, 14                                     # HoWo not a multiple of 4
+    hid = rnd(B, 1024, H, W, seed=1)
+    hs = _split(hid, dev)
+    for n, co in ((0, 10), (2, 1), (3, 8)):
+        w, b = rnd(co, 256, 1, 1, seed=4 + n, scale=1 / 16), rnd(co, seed=5)
+        raw = F.conv2d(hid[:, 256 * n:256 * (n + 1)], w, b)
+        pc = packing.pack_conv_bf16(w, b, [packing.Source(256, 1024, 256 * n)]).to(dev)
+        scale = float(raw.abs().max())
+        got = ops.conv2d_bf16x3(pc, [hs], B, H, W, layout=1)
+        assert float((got.cpu() - raw).abs().max()) < 3e-5 * scale
+        got = ops.conv2d_bf16x3(pc, [hs], B, H, W, layout=1, act=2)
+        close(got, torch.clamp(torch.sigmoid(raw), 1e-4, 1 - 1e-4), 1e-4, 1e-5)
+        o1, o2 = ops.conv2d_bf16x3(pc, [hs], B, H, W, layout=1, act=3)
+        assert float((o1.cpu() - raw).abs().max()) < 3e-5 * scale
+        close(o2, 1.0 / (torch.sigmoid(raw) + 1e-6) - 1.0, 1e-3, 1e-3)
