@@ -244,9 +244,11 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, bool PRECISE>
 __global__ __launch_bounds__(256) void dcn_igemm_kernel(DcnK p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int RA = BM / 32, RB = BN / 32;
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * CF_LDS_STRIDE];
+  // LDS: A tile | B tile | sampling descriptors {h, w, sigmoid(mask), -} per (tile row, tap)
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * CF_LDS_STRIDE + BM * 9 * 4];
   float* As = smem;
   float* Bs = smem + BM * CF_LDS_STRIDE;
+  f32x4* desc = reinterpret_cast<f32x4*>(smem + (BM + BN) * CF_LDS_STRIDE);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -256,16 +258,29 @@ __global__ __launch_bounds__(256) void dcn_igemm_kernel(DcnK p) {
   const int tr = tid >> 3, ts = tid & 7;
   const int HW = p.H * p.W;
 
-  int ho[RA], wo[RA], boff[RA], mrow[RA];
+  // ---- once per tile: sampling position and modulation of every (pixel, tap).  The offsets,
+  // the floor/weights and above all the sigmoid are shared by all channel chunks of a tap.
+  for (int i = tid; i < BM * 9; i += 256) {
+    const int r = i / 9, tap = i - r * 9;
+    const int m = m0 + r;
+    f32x4 d = {-1.0e9f, -1.0e9f, 0.0f, 0.0f};
+    if (m < p.ep.M) {
+      const int b = m / HW, rem = m - b * HW;
+      const int ho = rem / p.W, wo = rem - ho * p.W;
+      const float* om = p.om + (size_t)m * p.om_stride;
+      const int ti = tap / 3, tj = tap - ti * 3;
+      d[0] = (float)(ho - 1 + ti) + om[2 * tap];
+      d[1] = (float)(wo - 1 + tj) + om[2 * tap + 1];
+      d[2] = cf_sigmoid(om[18 + tap]);
+    }
+    desc[i] = d;
+  }
+
+  int boff[RA];
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
     const int m = m0 + tr + 32 * j;
-    mrow[j] = m < p.ep.M ? m : -1;
-    const int mm = m < p.ep.M ? m : 0;
-    const int b = mm / HW, rem = mm - b * HW;
-    ho[j] = rem / p.W;
-    wo[j] = rem - ho[j] * p.W;
-    boff[j] = b * HW;
+    boff[j] = (m < p.ep.M ? m / HW : 0) * HW;
   }
 
   f32x16 acc[TM][TN];
@@ -275,41 +290,47 @@ __global__ __launch_bounds__(256) void dcn_igemm_kernel(DcnK p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  __syncthreads();
 
-  for (int c = 0; c < p.n_chunks; ++c) {
+  // Software pipeline: the four corner rows of chunk c+1 (and its weight chunk) are requested
+  // before the MFMAs of chunk c and combined after them.
+  f32x4 cv[RA][4], cw[RA], rb[RB];
+  auto issue = [&](int c) {
     const int tap = c / p.chunks_per_tap;
     const int c0 = (c - tap * p.chunks_per_tap) * CF_BK + ts * 4;
-    const int ti = tap / 3, tj = tap - ti * 3;
-    f32x4 ra[RA], rb[RB];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (mrow[j] >= 0) {
-        const float* om = p.om + (size_t)mrow[j] * p.om_stride;
-        const float dy = om[2 * tap], dx = om[2 * tap + 1];
-        const float mk = cf_sigmoid(om[18 + tap]);
-        const float hf = (float)(ho[j] - 1 + ti) + dy;
-        const float wf = (float)(wo[j] - 1 + tj) + dx;
-        if (hf > -1.0f && hf < (float)p.H && wf > -1.0f && wf < (float)p.W) {
-          const float hfl = floorf(hf), wfl = floorf(wf);
-          const int hl = (int)hfl, wl = (int)wfl;
-          const float lh = hf - hfl, lw = wf - wfl, hh = 1.0f - lh, hw = 1.0f - lw;
-          const float* base = p.x + (size_t)boff[j] * p.C + c0;
-          const bool t_ok = hl >= 0, b_ok = hl + 1 <= p.H - 1, l_ok = wl >= 0, r_ok = wl + 1 <= p.W - 1;
-          f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
-          if (t_ok && l_ok) v1 = *reinterpret_cast<const f32x4*>(base + (size_t)(hl * p.W + wl) * p.C);
-          if (t_ok && r_ok) v2 = *reinterpret_cast<const f32x4*>(base + (size_t)(hl * p.W + wl + 1) * p.C);
-          if (b_ok && l_ok) v3 = *reinterpret_cast<const f32x4*>(base + (size_t)((hl + 1) * p.W + wl) * p.C);
-          if (b_ok && r_ok) v4 = *reinterpret_cast<const f32x4*>(base + (size_t)((hl + 1) * p.W + wl + 1) * p.C);
-          const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-          v = (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4) * mk;
-        }
-      }
-      ra[j] = v;
+      const f32x4 d = desc[(tr + 32 * j) * 9 + tap];
+      const float hf = d[0], wf = d[1];
+      const bool inside = hf > -1.0f && hf < (float)p.H && wf > -1.0f && wf < (float)p.W;
+      const float hfl = floorf(hf), wfl = floorf(wf);
+      const int hl = (int)hfl, wl = (int)wfl;
+      const float lh = hf - hfl, lw = wf - wfl, hh = 1.0f - lh, hw = 1.0f - lw;
+      const bool t_ok = inside && hl >= 0, b_ok = inside && hl + 1 <= p.H - 1;
+      const bool l_ok = wl >= 0, r_ok = wl + 1 <= p.W - 1;
+      const float* base = p.x + (size_t)boff[j] * p.C + c0;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      cv[j][0] = (t_ok && l_ok) ? *reinterpret_cast<const f32x4*>(base + (size_t)(hl * p.W + wl) * p.C) : z;
+      cv[j][1] = (t_ok && r_ok) ? *reinterpret_cast<const f32x4*>(base + (size_t)(hl * p.W + wl + 1) * p.C) : z;
+      cv[j][2] = (b_ok && l_ok) ? *reinterpret_cast<const f32x4*>(base + (size_t)((hl + 1) * p.W + wl) * p.C) : z;
+      cv[j][3] = (b_ok && r_ok) ? *reinterpret_cast<const f32x4*>(base + (size_t)((hl + 1) * p.W + wl + 1) * p.C) : z;
+      const f32x4 w = {hh * hw, hh * lw, lh * hw, lh * lw};
+      cw[j] = w;  // the mask is applied after the 4-corner sum, as the reference does
     }
     const float* wp = p.weight + (size_t)(n0 + tr) * p.K_pad + c * CF_BK + ts * 4;
 #pragma unroll
     for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(wp + (size_t)(32 * j) * p.K_pad);
+  };
+
+  issue(0);
+  for (int c = 0; c < p.n_chunks; ++c) {
+    const int tap = c / p.chunks_per_tap;
+    f32x4 ra[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const float mk = desc[(tr + 32 * j) * 9 + tap][2];
+      ra[j] = (cw[j][0] * cv[j][0] + cw[j][1] * cv[j][1] + cw[j][2] * cv[j][2] + cw[j][3] * cv[j][3]) * mk;
+    }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RA; ++j)
@@ -318,6 +339,7 @@ __global__ __launch_bounds__(256) void dcn_igemm_kernel(DcnK p) {
     for (int j = 0; j < RB; ++j)
       *reinterpret_cast<f32x4*>(&Bs[(tr + 32 * j) * CF_LDS_STRIDE + ts * 4]) = rb[j];
     __syncthreads();
+    if (c + 1 < p.n_chunks) issue(c + 1);
     mma_chunk<TM, TN, PRECISE>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
   }
   epilogue<TM, TN>(p.ep, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, acc);
@@ -347,9 +369,10 @@ TileCfg pick_tile(long M, int N_pad) {
     else hipLaunchKernelGGL((KERNEL<BM_, BN_, WM_, WN_, false>), dim3(MT * NT), dim3(256), 0, st, ARGS); \
   } while (0)
 
-#define DISPATCH_TILE(KERNEL, ARGS)                                        \
+#define DISPATCH_TILE(KERNEL, ARGS, FORCE_BM64)                            \
   do {                                                                     \
-    const TileCfg t = pick_tile(M, N_pad);                                 \
+    TileCfg t = pick_tile(M, N_pad);                                       \
+    if ((FORCE_BM64) && t.bn >= 64) t.bm = 64;                             \
     if (t.bm == 128 && t.bn == 128) LAUNCH_TILE(KERNEL, ARGS, 128, 128, 2, 2); \
     else if (t.bm == 128 && t.bn == 64) LAUNCH_TILE(KERNEL, ARGS, 128, 64, 2, 2); \
     else if (t.bm == 128 && t.bn == 32) LAUNCH_TILE(KERNEL, ARGS, 128, 32, 4, 1); \
@@ -387,7 +410,7 @@ extern "C" int cf_conv2d_fused(const cf_conv_args* a, void* stream) {
   const int N_pad = a->N_pad;
   const bool precise = a->precise != 0;
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_TILE(conv_igemm_kernel, k);
+  DISPATCH_TILE(conv_igemm_kernel, k, false);
   return cf_check_launch("cf_conv2d_fused");
 }
 
@@ -411,6 +434,7 @@ extern "C" int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream) {
   const int N_pad = a->N_pad;
   const bool precise = a->precise != 0;
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_TILE(dcn_igemm_kernel, k);
+  // 64-row tiles: the pipelined gather holds 4 corner rows per staged pixel row in registers
+  DISPATCH_TILE(dcn_igemm_kernel, k, true);
   return cf_check_launch("cf_dcn_v2_fused");
 }

@@ -585,6 +585,26 @@ class DLASeg(nn.Module):
                 plan.timed[idx] = []
         return out, flops
 
+    def time_all(self, on=True):
+        """Bracket EVERY launch of every plan with HIP events (dev tool: tools/layer_times.py)."""
+        for plan in self._plans.values():
+            plan.timed = {i: [] for i in range(len(plan.steps))} if on else {}
+
+    def all_launch_times(self):
+        """-> [(step name or kernel entry point, mean ms, algorithmic FLOPs)] in launch order."""
+        torch.cuda.synchronize()
+        plan = list(self._plans.values())[-1]
+        names = {v: k for k, v in plan.step_index.items()}
+        out = []
+        for i, step in enumerate(plan.steps):
+            ev = plan.timed.get(i, [])
+            if not ev:
+                continue
+            ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            nm = names.get(i, step[0].__name__)
+            out.append((nm, ms, plan.step_flops.get(names.get(i, ""), 0.0)))
+        return out
+
     def conv_flops_per_forward(self):
         """Algorithmic FLOPs (2*MACs) of all conv / DCN launches of the newest plan."""
         plan = list(self._plans.values())[-1]
