@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   constexpr int RA = BM / 32, RB = BN / 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * CF_LDS_STRIDE];
+  extern __shared__ __attribute__((aligned(16))) cf_slot lds_slots[];  // the layer's slot table
   float* As = smem;
   float* Bs = smem + BM * CF_LDS_STRIDE;
 
@@ -173,6 +174,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
   const int mt = lid / p.NT, nt = lid - mt * p.NT;
   const int m0 = mt * BM, n0 = nt * BN;
   const int tr = tid >> 3, ts = tid & 7;
+  for (int i = tid; i < p.n_chunks * 8; i += 256) lds_slots[i] = p.slots[i];
+  __syncthreads();
 
   // per-thread staging rows: pixel -> top-left input coordinate
   int y0[RA], x0[RA], boff[RA];
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 
   f32x4 ra[RA], rb[RB];
   auto load_chunk = [&](int c) {
-    const cf_slot sl = p.slots[c * 8 + ts];
-    const int src = __builtin_amdgcn_readfirstlane(p.slots[c * 8].src);
+    const cf_slot sl = lds_slots[c * 8 + ts];
+    const int src = __builtin_amdgcn_readfirstlane(lds_slots[c * 8].src);
     const float* sp = src == 1 ? p.src[1] : src == 2 ? p.src[2] : src == 3 ? p.src[3] : p.src[0];
     const int sc = src == 1 ? p.src_c[1] : src == 2 ? p.src_c[2] : src == 3 ? p.src_c[3] : p.src_c[0];
 #pragma unroll
@@ -349,6 +352,19 @@ struct TileCfg {
   int bm, bn;
 };
 
+// Launch with `dyn` bytes of dynamic LDS on top of the kernel's static tiles (raises the kernel's
+// dynamic-LDS limit once per instantiation; 160 KiB per workgroup are available on gfx950).
+template <typename K, typename A>
+void launch_dyn(K kernel, int blocks, size_t dyn, hipStream_t st, const A& args) {
+  static size_t limit = 0;  // one per template instantiation
+  if (dyn > limit) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(dyn < 32768 ? 32768 : dyn));
+    limit = dyn < 32768 ? 32768 : dyn;
+  }
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), dyn, st, args);
+}
+
 // Tile choice: widest N tile that divides N_pad; drop to 64-row tiles when the grid would not
 // give every CU (256) at least two workgroups.
 TileCfg pick_tile(long M, int N_pad) {
@@ -365,8 +381,8 @@ TileCfg pick_tile(long M, int N_pad) {
   do {                                                                                  \
     const int MT = (int)((M + BM_ - 1) / BM_), NT = N_pad / BN_;                        \
     ARGS.NT = NT;                                                                       \
-    if (precise) hipLaunchKernelGGL((KERNEL<BM_, BN_, WM_, WN_, true>), dim3(MT * NT), dim3(256), 0, st, ARGS);   \
-    else hipLaunchKernelGGL((KERNEL<BM_, BN_, WM_, WN_, false>), dim3(MT * NT), dim3(256), 0, st, ARGS); \
+    if (precise) launch_dyn((KERNEL<BM_, BN_, WM_, WN_, true>), MT * NT, dyn_lds, st, ARGS);    \
+    else launch_dyn((KERNEL<BM_, BN_, WM_, WN_, false>), MT * NT, dyn_lds, st, ARGS);           \
   } while (0)
 
 #define DISPATCH_TILE(KERNEL, ARGS, FORCE_BM64)                            \
@@ -409,8 +425,10 @@ extern "C" int cf_conv2d_fused(const cf_conv_args* a, void* stream) {
                       a->out_layout, a->act, (int)M, a->N, a->Ho * a->Wo};
   const int N_pad = a->N_pad;
   const bool precise = a->precise != 0;
+  const size_t dyn_lds = (size_t)(a->K_pad / 4) * sizeof(cf_slot);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_TILE(conv_igemm_kernel, k, false);
+  // PRECISE doubles the accumulator registers: 64-row tiles keep three workgroups per CU
+  DISPATCH_TILE(conv_igemm_kernel, k, precise);
   return cf_check_launch("cf_conv2d_fused");
 }
 
@@ -433,6 +451,7 @@ extern "C" int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream) {
                       (int)M, a->N, a->H * a->W};
   const int N_pad = a->N_pad;
   const bool precise = a->precise != 0;
+  const size_t dyn_lds = 0;
   hipStream_t st = (hipStream_t)stream;
   // 64-row tiles: the pipelined gather holds 4 corner rows per staged pixel row in registers
   DISPATCH_TILE(dcn_igemm_kernel, k, true);
