@@ -30,6 +30,19 @@ class DcnArgs(C.Structure):
                 ("act", C.c_int32), ("precise", C.c_int32)]
 
 
+CF_MAX_HEADS = 12
+
+
+class HeadTailArgs(C.Structure):
+    _fields_ = [("x", _f), ("x_stride", C.c_int32), ("B", C.c_int32), ("H", C.c_int32),
+                ("W", C.c_int32), ("n_heads", C.c_int32), ("n_hidden", C.c_int32),
+                ("w_hidden", (_f * 2) * CF_MAX_HEADS), ("b_hidden", (_f * 2) * CF_MAX_HEADS),
+                ("w_out", _f * CF_MAX_HEADS), ("b_out", _f * CF_MAX_HEADS),
+                ("out", _f * CF_MAX_HEADS), ("out2", _f * CF_MAX_HEADS),
+                ("c_base", C.c_int32 * CF_MAX_HEADS), ("n_out", C.c_int32 * CF_MAX_HEADS),
+                ("act", C.c_int32 * CF_MAX_HEADS)]
+
+
 class DecodeArgs(C.Structure):
     _fields_ = [("scores", _f), ("inds", _f), ("classes", _f), ("reg", _f), ("wh", _f),
                 ("depth", _f), ("rot", _f), ("dim", _f), ("amodal", _f), ("att", _f), ("vel", _f),
@@ -43,6 +56,7 @@ SYMBOLS = {
     "cf_conv2d_fused": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_conv2d_bf16x3": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_split_bf16": (_i, [_f, _f, C.c_long, _i, _i, _i, _f]),
+    "cf_head_tail": (_i, [C.POINTER(HeadTailArgs), _f]),
     "cf_dcn_v2_fused": (_i, [C.POINTER(DcnArgs), _f]),
     "cf_upsample_dw": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "cf_maxpool2x2": (_i, [_f, _f, _i, _i, _i, _i, _f]),

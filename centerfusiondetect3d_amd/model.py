@@ -322,8 +322,29 @@ class _Plan:
             feat_in = feat
         hs = 256 * len(primary)
         hid = hconv("heads.primary.0", [feat_in], [64], out_c=hs)
-        for h in primary:
-            head_out(h, hid, hs)
+
+        def act_of(h):
+            return ACT_SIGMOID_CLAMP if h == "heatmap" else (
+                ACT_RAW_AND_SIGDEPTH if h in ("depth", "depth2") else ACT_NONE)
+
+        def fused_tails(name, names, src, stride):
+            """One cf_head_tail launch for sibling heads; per-call outputs patched via self.tails."""
+            hd = [dict(pk[name][h], c_base=256 * n, act=act_of(h)) for n, h in enumerate(names)]
+            a = ops.head_tail_args(src, stride, B, h4, w4, hd)
+            self.keep.append(a)
+            for n, h in enumerate(names):
+                self.tails[h] = (a, n)
+            self.step_index[name] = len(self.steps)
+            self.step_flops[name] = sum(2.0 * M4 * 256 * (256 * len(pk[name][h]["w_hidden"]) + heads[h])
+                                        for h in names)
+            self.steps.append((self.lib.cf_head_tail, C.byref(a)))
+
+        self.tails = {}
+        if bf:
+            fused_tails("tails.primary", primary, hid, hs)
+        else:
+            for h in primary:
+                head_out(h, hid, hs)
         if radar:
             self.tk_scores = buf(B, K)
             self.tk_inds = buf(B, K, dtype=torch.int32)
@@ -336,11 +357,14 @@ class _Plan:
             ss = 256 * len(SECONDARY_HEADS)
             s1 = hconv("heads.secondary.0", [feat_in, self.pc_hm8 if bf else self.pc_hm4],
                        [64, 8 if bf else 4], out_c=ss)
-            s2 = buf(B, h4, w4, 2, ss, dtype=torch.bfloat16) if bf else buf(B, h4, w4, ss)
-            for n, h in enumerate(SECONDARY_HEADS):
-                hconv(f"heads.{h}.2", [s1], [ss], out=s2, out_offset=256 * n)
-                hconv(f"heads.{h}.4", [s2], [ss], out=s1, out_offset=256 * n)
-                head_out(h, s1, ss)
+            if bf:
+                fused_tails("tails.secondary", SECONDARY_HEADS, s1, ss)
+            else:
+                s2 = buf(B, h4, w4, ss)
+                for n, h in enumerate(SECONDARY_HEADS):
+                    hconv(f"heads.{h}.2", [s1], [ss], out=s2, out_offset=256 * n)
+                    hconv(f"heads.{h}.4", [s2], [ss], out=s1, out_offset=256 * n)
+                    head_out(h, s1, ss)
 
     # ------------------------------------------------------------------------------------------
     def run(self, model, x, pc_dep, calib):
@@ -351,14 +375,23 @@ class _Plan:
         heads = model.config.heads
         y = {}
         new = lambda c: torch.empty((B, c, h4, w4), device=dev, dtype=torch.float32)
+        def set_out(h, t, second=False):
+            if h in self.tails:
+                a, n = self.tails[h]
+                (a.out2 if second else a.out)[n] = t.data_ptr()
+            elif second:
+                self.outs[h].out2 = t.data_ptr()
+            else:
+                self.outs[h].out = t.data_ptr()
+
         for h in self.primary:
             t = new(heads[h])
             y[h] = t
-            self.outs[h].out = t.data_ptr()
+            set_out(h, t)
         depth_raw = y["depth"]                             # raw logits; "depth" gets the sigmoid form
         y["depthMap"] = depth_raw
         y["depth"] = new(1)
-        self.outs["depth"].out2 = y["depth"].data_ptr()
+        set_out("depth", y["depth"], second=True)
         y["calib"] = calib
         self.steps[self.in_step] = (lib.cf_nchw_to_nhwc4, x.data_ptr(), self.x4.data_ptr(), B, 3, H, W)
         if self.radar:
@@ -378,11 +411,11 @@ class _Plan:
             for h in SECONDARY_HEADS:
                 t = new(heads[h])
                 y[h] = t
-                self.outs[h].out = t.data_ptr()
+                set_out(h, t)
             y["pc_hm_out"] = pc_hm[:, :1]
             y["depthMap"] = y["depth2"]                    # raw depth2 logits (detectHeads.py:188-190)
             y["depth2"] = new(1)
-            self.outs["depth2"].out2 = y["depth2"].data_ptr()
+            set_out("depth2", y["depth2"], second=True)
         if self.timed:
             for i, step in enumerate(self.steps):
                 ev = self.timed.get(i)
@@ -530,6 +563,18 @@ class DLASeg(nn.Module):
                 for idx in (2, 4):
                     pk[f"heads.{h}.{idx}"] = pack(hw(h, idx), hb(h, idx), [Source(256, ns, 256 * n)]).to(device)
                 pk[f"heads.{h}.out"] = pack(hw(h, 6), hb(h, 6), [Source(256, ns, 256 * n)]).to(device)
+        if bf:
+            def tail(h, hidden_idx, out_idx):
+                n_out = heads[h]
+                b32 = torch.zeros(32)
+                b32[:n_out] = hb(h, out_idx)
+                return dict(w_hidden=[packing.pack_fragments(hw(h, i).view(256, 256)).to(device) for i in hidden_idx],
+                            b_hidden=[hb(h, i).to(device) for i in hidden_idx],
+                            w_out=packing.pack_fragments(hw(h, out_idx).view(n_out, 256)).to(device),
+                            b_out=b32.to(device), n_out=n_out)
+            pk["tails.primary"] = {h: tail(h, [], 2) for h in primary}
+            if radar:
+                pk["tails.secondary"] = {h: tail(h, [2, 4], 6) for h in SECONDARY_HEADS}
         self._packed = pk
 
     # ----------------------------------------------------------------------------------- forward

@@ -104,6 +104,28 @@ def conv2d_bf16x3(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, layout=LAYOUT_NHW
     return (out, out2) if act == ACT_RAW_AND_SIGDEPTH else out
 
 
+def head_tail_args(x, x_stride, B, H, W, heads):
+    """heads: list of dicts {c_base, w_hidden:[frag tensors], b_hidden:[f32 tensors], w_out, b_out,
+    n_out, act, out (NCHW tensor or None), out2}.  Outputs may be patched later (a.out[i] = ptr)."""
+    a = _lib.HeadTailArgs()
+    a.x, a.x_stride, a.B, a.H, a.W = x.data_ptr(), x_stride, B, H, W
+    a.n_heads = len(heads)
+    a.n_hidden = len(heads[0]["w_hidden"])
+    for i, hd in enumerate(heads):
+        assert len(hd["w_hidden"]) == a.n_hidden
+        for l, (w, b) in enumerate(zip(hd["w_hidden"], hd["b_hidden"])):
+            a.w_hidden[i][l], a.b_hidden[i][l] = w.data_ptr(), b.data_ptr()
+        a.w_out[i], a.b_out[i] = hd["w_out"].data_ptr(), hd["b_out"].data_ptr()
+        a.out[i] = _lib.ptr(hd.get("out"))
+        a.out2[i] = _lib.ptr(hd.get("out2"))
+        a.c_base[i], a.n_out[i], a.act[i] = hd["c_base"], hd["n_out"], hd["act"]
+    return a
+
+
+def run_head_tail(a):
+    _lib.check(_lib.load().cf_head_tail(C.byref(a), _lib.stream_ptr()), "cf_head_tail")
+
+
 def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act=ACT_RELU,
              precise=True):
     a = _lib.DcnArgs()

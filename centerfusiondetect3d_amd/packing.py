@@ -132,6 +132,23 @@ def pack_conv_bf16(weight, bias, sources: Sequence[Source], stride=1, pad=None, 
                       co, n_pad, k_pad, kh, stride, pad, tuple(s.channels for s in sources))
 
 
+def pack_fragments(weight2d, n_pad=None):
+    """(N, K) fp32 -> MFMA A-operand fragment order for cf_head_tail:
+    uint8 view of [N_pad/32][K/16][2 (hi, lo)][64 lanes][8 bf16]; lane (i = l & 31, h = l >> 5)
+    holds W[32 rt + i][16 ks + 8 h + j], j = 0..7."""
+    n, k = weight2d.shape
+    assert k % 16 == 0
+    n_pad = n_pad or ((n + 31) // 32) * 32
+    w = torch.zeros(n_pad, k)
+    w[:n] = weight2d.float()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    planes = torch.stack([hi, lo], 0)                                   # (2, N, K)
+    f = planes.view(2, n_pad // 32, 32, k // 16, 2, 8)                  # p, rt, i, ks, h, j
+    f = f.permute(1, 3, 0, 4, 2, 5).contiguous()                        # rt, ks, p, h, i, j
+    return f.view(n_pad // 32, k // 16, 2, 64, 8)
+
+
 @dataclass
 class PackedDcn:
     weight: torch.Tensor   # [N_pad, 9*C]  k = tap*C + c

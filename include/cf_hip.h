@@ -93,6 +93,34 @@ int cf_conv2d_bf16x3(const cf_conv_args* a, void* stream);
 /* cf_split_bf16: fp32 NHWC [M][in_stride] (C used) -> split-bf16 [M][2][Cs], channels C..Cs-1 zero. */
 int cf_split_bf16(const float* x, void* out, long M, int C, int in_stride, int Cs, void* stream);
 
+/* cf_head_tail: fused tail of up to CF_MAX_HEADS sibling heads:  x -> [ReLU(W x + b)] x n_hidden -> W_out x
+ * + b_out (+ head activation), hidden width 256, on the bf16 MFMA pipe with split operands.  The
+ * hidden maps stay in LDS (64-pixel tiles); only the (B, n_out, H, W) fp32 NCHW maps are written.
+ * replaces the 1x1 layers of model/networks/detectHeads.py:64-71, 80-90 (one launch instead of
+ * 3 per secondary head / 1 per primary head, and no hidden-map round trips through HBM).
+ * x: split-bf16 NHWC (B,H,W,2,x_stride); head i reads channels [c_base[i], c_base[i]+256).
+ * w_hidden / w_out: weights in MFMA fragment order (centerfusiondetect3d_amd/packing.py:
+ * pack_fragments): [row tile of 32][k step of 16][hi,lo][lane 64][8 bf16]; w_out is one row tile
+ * (n_out <= 32, zero padded); b_out has 32 floats. */
+#define CF_MAX_HEADS 12
+typedef struct cf_head_tail_args {
+  const void* x;
+  int32_t x_stride;
+  int32_t B, H, W;
+  int32_t n_heads;
+  int32_t n_hidden;                        /* 0..2 hidden 256->256 layers per head */
+  const void* w_hidden[CF_MAX_HEADS][2];
+  const float* b_hidden[CF_MAX_HEADS][2];
+  const void* w_out[CF_MAX_HEADS];
+  const float* b_out[CF_MAX_HEADS];
+  float* out[CF_MAX_HEADS];
+  float* out2[CF_MAX_HEADS];               /* second output of CF_ACT_RAW_AND_SIGDEPTH heads, else NULL */
+  int32_t c_base[CF_MAX_HEADS];
+  int32_t n_out[CF_MAX_HEADS];
+  int32_t act[CF_MAX_HEADS];
+} cf_head_tail_args;
+int cf_head_tail(const cf_head_tail_args* a, void* stream);
+
 /* cf_dcn_v2_fused: modulated deformable 3x3 convolution (stride 1, pad 1, dil 1, groups 1) with
  * the bilinear gather fused into the GEMM A-tile staging, + bias(BN folded) + ReLU.
  * replaces torchvision.ops.deform_conv2d + BN + ReLU of model/networks/dla.py:456-472.

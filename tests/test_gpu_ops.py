@@ -364,3 +364,41 @@ def test_conv2d_bf16x3_nchw_outputs_and_slices(dev):
         o1, o2 = ops.conv2d_bf16x3(pc, [hs], B, H, W, layout=1, act=3)
         assert float((o1.cpu() - raw).abs().max()) < 3e-5 * scale
         close(o2, 1.0 / (torch.sigmoid(raw) + 1e-6) - 1.0, 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("n_hidden,B,H,W", [(0, 2, 9, 14), (2, 1, 16, 20), (1, 2, 7, 9)])
+def test_head_tail_fused_chain(dev, n_hidden, B, H, W):
+    """x -> [relu(W x + b)] x n_hidden -> W_out x + b_out, several sibling heads in one launch,
+    hidden tile resident in LDS; checked against plain fp32 torch."""
+    from centerfusiondetect3d_amd import ops, packing
+    n_outs, acts = [10, 1, 8, 3], [2, 3, 0, 0]
+    hid = F.relu(rnd(B, 256 * len(n_outs), H, W, seed=1))
+    hs = _split(hid, dev)
+    heads, refs, keep = [], [], []
+    for i, (no, act) in enumerate(zip(n_outs, acts)):
+        x = hid[:, 256 * i:256 * (i + 1)]
+        wh, bh = [], []
+        for l in range(n_hidden):
+            w, b = rnd(256, 256, 1, 1, seed=10 * i + l, scale=1 / 16), rnd(256, seed=50 + 10 * i + l, scale=0.1)
+            x = F.relu(F.conv2d(x, w, b))
+            wh.append(packing.pack_fragments(w.view(256, 256)).to(dev)); bh.append(b.to(dev))
+        w, b = rnd(no, 256, 1, 1, seed=100 + i, scale=1 / 16), rnd(no, seed=200 + i)
+        raw = F.conv2d(x, w, b)
+        b32 = torch.zeros(32); b32[:no] = b
+        out = torch.full((B, no, H, W), float("nan"), device=dev)
+        out2 = torch.full((B, no, H, W), float("nan"), device=dev) if act == 3 else None
+        heads.append(dict(c_base=256 * i, w_hidden=wh, b_hidden=bh, w_out=packing.pack_fragments(w.view(no, 256)).to(dev),
+                          b_out=b32.to(dev), n_out=no, act=act, out=out, out2=out2))
+        refs.append(raw)
+    a = ops.head_tail_args(hs, 256 * len(n_outs), B, H, W, heads)
+    ops.run_head_tail(a)
+    for hd, raw in zip(heads, refs):
+        scale = float(raw.abs().max())
+        tol = 6e-5 * scale * (1 + n_hidden)
+        got = hd["out"].cpu()
+        if hd["act"] == 2:
+            close(got, torch.clamp(torch.sigmoid(raw), 1e-4, 1 - 1e-4), 1e-4, 1e-5)
+        else:
+            assert float((got - raw).abs().max()) < tol, float((got - raw).abs().max()) / scale
+        if hd["act"] == 3:
+            close(hd["out2"], 1.0 / (torch.sigmoid(raw) + 1e-6) - 1.0, 1e-3, 1e-3)
