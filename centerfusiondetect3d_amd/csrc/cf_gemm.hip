@@ -365,13 +365,15 @@ void launch_dyn(K kernel, int blocks, size_t dyn, hipStream_t st, const A& args)
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), dyn, st, args);
 }
 
-// Tile choice: widest N tile that divides N_pad; drop to 64-row tiles when the grid would not
-// give every CU (256) at least two workgroups.
+// Tile choice: widest N tile that divides N_pad; 128-row tiles only when the grid still gives every
+// CU (256) at least two workgroups; and when even 64-row tiles leave some CUs with one workgroup
+// while their neighbours hold two (small-M layers: level5, 14x25 / 28x50 neck nodes), halve the N tile.
 TileCfg pick_tile(long M, int N_pad) {
   TileCfg t;
   t.bn = (N_pad % 128 == 0) ? 128 : (N_pad % 64 == 0) ? 64 : 32;
   const long blocks128 = ((M + 127) / 128) * (N_pad / t.bn);
   t.bm = blocks128 >= 512 ? 128 : 64;
+  if (t.bm == 64 && t.bn == 128 && ((M + 63) / 64) * (N_pad / 128) < 512) t.bn = 64;
   return t;
 }
 

@@ -12,6 +12,7 @@
 // Weights: [N_pad][2][K_pad] bf16.  GEMM/tiling/LDS-padding logic mirrors cf_gemm.hip: BM x 32 A
 // chunk and BN x 32 weight chunk per step, rows padded to 80 bytes per plane (conflict-free
 // ds_read_b128), 4 waves x (TM x TN) 32x32 accumulators, next chunk prefetched to registers.
+#include <stdlib.h>
 #include "cf_common.h"
 
 namespace {
@@ -19,7 +20,6 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int ROWB = 80;  // LDS bytes per row per plane (32 bf16 + 16 B pad)
 
 struct ConvB {
   const unsigned char* src[CF_MAX_SRC];
@@ -45,8 +45,13 @@ __device__ __forceinline__ float act_f(float v, int act) {
   return v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// BK = K depth staged per main-loop step (32 or 64 bf16).  LDS rows are BK*2 + 16 bytes per plane:
+// an odd number of 16-byte slots, so the 16 rows a ds_read_b128 lane group touches never collide.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
 __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvB p) {
+  constexpr int ROWB = BK * 2 + 16;
+  constexpr int UPR = BK / 8;        // 16-byte units per row per plane
+  constexpr int UPT = UPR / 4;       // units each staging thread moves per row (1 or 2)
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int RA = BM / 32, RB = BN / 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -79,25 +84,31 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvB p) {
     }
   }
 
-  u32x4 ra[RA], rb[RB];
+  u32x4 ra[UPT][RA], rb[UPT][RB];
   auto load_chunk = [&](int c) {
-    const cf_slot sl = p.slots[c * 4 + unit];
-    const int src = __builtin_amdgcn_readfirstlane(p.slots[c * 4].src);
-    const unsigned char* sp = src == 1 ? p.src[1] : src == 2 ? p.src[2] : src == 3 ? p.src[3] : p.src[0];
-    const int sc = src == 1 ? p.src_c[1] : src == 2 ? p.src_c[2] : src == 3 ? p.src_c[3] : p.src_c[0];
 #pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      const int y = y0[j] + sl.dy, x = x0[j] + sl.dx;
-      const bool ok = (src >= 0) && (sl.c_off >= 0) && ((unsigned)y < (unsigned)p.H) &&
-                      ((unsigned)x < (unsigned)p.W);
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ok)
-        v = *reinterpret_cast<const u32x4*>(sp + ((size_t)(boff[j] + y * p.W + x) * (2 * sc) + plane * sc + sl.c_off) * 2);
-      ra[j] = v;
+    for (int u = 0; u < UPT; ++u) {
+      const int un = unit + 4 * u;                       // unit inside the BK-wide row
+      const int sidx = c * UPR + un;                     // slot index (8 channels per slot)
+      const cf_slot sl = p.slots[sidx];
+      // a 32-wide half-chunk never mixes sources (host packing), units un and un+4 may
+      const int src = __builtin_amdgcn_readfirstlane(p.slots[c * UPR + 4 * u].src);
+      const unsigned char* sp = src == 1 ? p.src[1] : src == 2 ? p.src[2] : src == 3 ? p.src[3] : p.src[0];
+      const int sc = src == 1 ? p.src_c[1] : src == 2 ? p.src_c[2] : src == 3 ? p.src_c[3] : p.src_c[0];
+#pragma unroll
+      for (int j = 0; j < RA; ++j) {
+        const int y = y0[j] + sl.dy, x = x0[j] + sl.dx;
+        const bool ok = (src >= 0) && (sl.c_off >= 0) && ((unsigned)y < (unsigned)p.H) &&
+                        ((unsigned)x < (unsigned)p.W);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok)
+          v = *reinterpret_cast<const u32x4*>(sp + ((size_t)(boff[j] + y * p.W + x) * (2 * sc) + plane * sc + sl.c_off) * 2);
+        ra[u][j] = v;
+      }
+      const unsigned char* wp = p.weight + (((size_t)(n0 + tr) * 2 + plane) * p.K_pad + c * BK + un * 8) * 2;
+#pragma unroll
+      for (int j = 0; j < RB; ++j) rb[u][j] = *reinterpret_cast<const u32x4*>(wp + (size_t)(32 * j) * 2 * p.K_pad * 2);
     }
-    const unsigned char* wp = p.weight + (((size_t)(n0 + tr) * 2 + plane) * p.K_pad + c * 32 + unit * 8) * 2;
-#pragma unroll
-    for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const u32x4*>(wp + (size_t)(32 * j) * 2 * p.K_pad * 2);
   };
 
   f32x16 acc[TM][TN];
@@ -113,15 +124,18 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvB p) {
   for (int c = 0; c < p.n_chunks; ++c) {
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RA; ++j)
-      *reinterpret_cast<u32x4*>(smem + plane * A_LO + (tr + 32 * j) * ROWB + unit * 16) = ra[j];
+    for (int u = 0; u < UPT; ++u) {
 #pragma unroll
-    for (int j = 0; j < RB; ++j)
-      *reinterpret_cast<u32x4*>(smem + B_HI + plane * (B_LO - B_HI) + (tr + 32 * j) * ROWB + unit * 16) = rb[j];
+      for (int j = 0; j < RA; ++j)
+        *reinterpret_cast<u32x4*>(smem + plane * A_LO + (tr + 32 * j) * ROWB + (unit + 4 * u) * 16) = ra[u][j];
+#pragma unroll
+      for (int j = 0; j < RB; ++j)
+        *reinterpret_cast<u32x4*>(smem + B_HI + plane * (B_LO - B_HI) + (tr + 32 * j) * ROWB + (unit + 4 * u) * 16) = rb[u][j];
+    }
     __syncthreads();
     if (c + 1 < p.n_chunks) load_chunk(c + 1);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < BK / 16; ++s) {
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
       const int koff = s * 32 + h * 16;
 #pragma unroll
@@ -269,22 +283,36 @@ extern "C" int cf_conv2d_bf16x3(const cf_conv_args* a, void* stream) {
   k.out2 = a->out2;
   k.H = a->H; k.W = a->W; k.Ho = a->Ho; k.Wo = a->Wo; k.stride = a->stride;
   k.K_pad = a->K_pad;
-  k.n_chunks = a->K_pad / 32;
   k.out_stride = a->out_stride; k.out_layout = a->out_layout; k.act = a->act;
   k.M = (int)M; k.N = a->N; k.HoWo = a->Ho * a->Wo;
   hipStream_t st = (hipStream_t)stream;
+  const int MT = (int)((M + 127) / 128);
+  // BK = 64 halves the barriers but measured 8 % slower than BK = 32 on the 3x3 head layers
+  // (2 workgroups per CU either way, longer exposed prologue): opt-in for experiments only.
+  static const bool want64 = getenv("CF_BF16_BK64") != nullptr;
+  const bool bk64 = (a->K_pad % 64 == 0) && want64;
+  k.n_chunks = a->K_pad / (bk64 ? 64 : 32);
   if (a->N_pad % 128 == 0) {
-    const int MT = (int)((M + 127) / 128);
     k.NT = a->N_pad / 128;
-    hipLaunchKernelGGL((conv_bf16x3_kernel<128, 128, 2, 2>), dim3(MT * k.NT), dim3(256), 0, st, k);
+    if (bk64) {
+      static bool once = false;
+      if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_kernel<128, 128, 2, 2, 64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+        once = true;
+      }
+      hipLaunchKernelGGL((conv_bf16x3_kernel<128, 128, 2, 2, 64>), dim3(MT * k.NT), dim3(256), 0, st, k);
+    } else {
+      hipLaunchKernelGGL((conv_bf16x3_kernel<128, 128, 2, 2, 32>), dim3(MT * k.NT), dim3(256), 0, st, k);
+    }
   } else if (a->N_pad % 64 == 0) {
-    const int MT = (int)((M + 127) / 128);
     k.NT = a->N_pad / 64;
-    hipLaunchKernelGGL((conv_bf16x3_kernel<128, 64, 2, 2>), dim3(MT * k.NT), dim3(256), 0, st, k);
+    k.n_chunks = a->K_pad / 32;
+    hipLaunchKernelGGL((conv_bf16x3_kernel<128, 64, 2, 2, 32>), dim3(MT * k.NT), dim3(256), 0, st, k);
   } else {
-    const int MT = (int)((M + 127) / 128);
     k.NT = a->N_pad / 32;
-    hipLaunchKernelGGL((conv_bf16x3_kernel<128, 32, 4, 1>), dim3(MT * k.NT), dim3(256), 0, st, k);
+    k.n_chunks = a->K_pad / 32;
+    hipLaunchKernelGGL((conv_bf16x3_kernel<128, 32, 4, 1, 32>), dim3(MT * k.NT), dim3(256), 0, st, k);
   }
   return cf_check_launch("cf_conv2d_bf16x3");
 }

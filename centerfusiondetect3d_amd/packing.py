@@ -118,6 +118,9 @@ def pack_conv_bf16(weight, bias, sources: Sequence[Source], stride=1, pad=None, 
             cols.append((-1, 0, 0, 0))
             n_slots += 1
         c_lo += s.channels
+    while len(slots) % 8:                  # whole 64-deep steps for the BK = 64 main loop
+        slots.append([len(sources) - 1, 0, 0, -1])
+        cols.append((-1, 0, 0, 0))
     k_pad = len(slots) * 8
     w = torch.zeros(n_pad, k_pad)
     wf = weight.float()
