@@ -43,6 +43,12 @@ class HeadTailArgs(C.Structure):
                 ("act", C.c_int32 * CF_MAX_HEADS)]
 
 
+class HeadFusedArgs(C.Structure):
+    _fields_ = [("tail", HeadTailArgs), ("src", _f * 2), ("src_c", C.c_int32 * 2), ("n_src", C.c_int32),
+                ("slots", _f), ("K_pad", C.c_int32), ("w_first", _f * CF_MAX_HEADS),
+                ("b_first", _f * CF_MAX_HEADS)]
+
+
 class DecodeArgs(C.Structure):
     _fields_ = [("scores", _f), ("inds", _f), ("classes", _f), ("reg", _f), ("wh", _f),
                 ("depth", _f), ("rot", _f), ("dim", _f), ("amodal", _f), ("att", _f), ("vel", _f),
@@ -57,6 +63,7 @@ SYMBOLS = {
     "cf_conv2d_bf16x3": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_split_bf16": (_i, [_f, _f, C.c_long, _i, _i, _i, _f]),
     "cf_head_tail": (_i, [C.POINTER(HeadTailArgs), _f]),
+    "cf_head_fused": (_i, [C.POINTER(HeadFusedArgs), _f]),
     "cf_dcn_v2_fused": (_i, [C.POINTER(DcnArgs), _f]),
     "cf_upsample_dw": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "cf_maxpool2x2": (_i, [_f, _f, _i, _i, _i, _i, _f]),

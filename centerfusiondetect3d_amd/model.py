@@ -321,7 +321,7 @@ class _Plan:
         else:
             feat_in = feat
         hs = 256 * len(primary)
-        hid = hconv("heads.primary.0", [feat_in], [64], out_c=hs)
+        hid = None if (bf and model.heads_fused) else hconv("heads.primary.0", [feat_in], [64], out_c=hs)
 
         def act_of(h):
             return ACT_SIGMOID_CLAMP if h == "heatmap" else (
@@ -339,8 +339,24 @@ class _Plan:
                                         for h in names)
             self.steps.append((self.lib.cf_head_tail, C.byref(a)))
 
+        def fused_heads(name, names, srcs, strides):
+            """One cf_head_fused launch: 3x3 + ReLU + tail for sibling heads, hidden never in HBM."""
+            hd = [dict(pk[name][h], act=act_of(h)) for h in names]
+            f = ops.head_fused_args(srcs, strides, hd[0]["slots"], hd[0]["k_pad"], B, h4, w4, hd)
+            self.keep.append(f)
+            for n, h in enumerate(names):
+                self.tails[h] = (f.tail, n)
+            self.step_index[name] = len(self.steps)
+            self.step_flops[name] = sum(
+                2.0 * M4 * 256 * (9 * sum(d["real_cin"]) + 256 * len(d["w_hidden"]) + heads[h])
+                for h, d in zip(names, hd))
+            self.steps.append((self.lib.cf_head_fused, C.byref(f)))
+
         self.tails = {}
-        if bf:
+        fuse_all = bf and bool(model.heads_fused)
+        if fuse_all:
+            fused_heads("tails.primary", primary, [feat_in], [64])
+        elif bf:
             fused_tails("tails.primary", primary, hid, hs)
         else:
             for h in primary:
@@ -355,6 +371,9 @@ class _Plan:
             self.topk_step = len(self.steps); self.steps.append(None)
             self.frustum_step = len(self.steps); self.steps.append(None)
             ss = 256 * len(SECONDARY_HEADS)
+            if fuse_all:
+                fused_heads("tails.secondary", SECONDARY_HEADS, [feat_in, self.pc_hm8], [64, 8])
+                return
             s1 = hconv("heads.secondary.0", [feat_in, self.pc_hm8 if bf else self.pc_hm4],
                        [64, 8 if bf else 4], out_c=ss)
             if bf:
@@ -468,6 +487,7 @@ class DLASeg(nn.Module):
         self._plans = {}
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)
+        self.heads_fused = True  # with heads_bf16: one launch per head group, hidden maps stay in LDS
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
         self.eval()
 
@@ -572,9 +592,14 @@ class DLASeg(nn.Module):
                             b_hidden=[hb(h, i).to(device) for i in hidden_idx],
                             w_out=packing.pack_fragments(hw(h, out_idx).view(n_out, 256)).to(device),
                             b_out=b32.to(device), n_out=n_out)
-            pk["tails.primary"] = {h: tail(h, [], 2) for h in primary}
+            def first(h, srcs):
+                pc = packing.pack_conv_bf16(hw(h, 0), hb(h, 0), srcs, fragments=True).to(device)
+                return dict(w_first=pc.weight, b_first=pc.bias[:256].contiguous(), slots=pc.slots, k_pad=pc.k_pad,
+                            real_cin=pc.real_cin)
+            pk["tails.primary"] = {h: dict(tail(h, [], 2), **first(h, [feat_src])) for h in primary}
             if radar:
-                pk["tails.secondary"] = {h: tail(h, [2, 4], 6) for h in SECONDARY_HEADS}
+                pk["tails.secondary"] = {h: dict(tail(h, [2, 4], 6), **first(h, [feat_src, pc_src]))
+                                         for h in SECONDARY_HEADS}
         self._packed = pk
 
     # ----------------------------------------------------------------------------------- forward

@@ -122,6 +122,24 @@ def head_tail_args(x, x_stride, B, H, W, heads):
     return a
 
 
+def head_fused_args(srcs, src_strides, slots, k_pad, B, H, W, heads):
+    """heads: as head_tail_args plus w_first (fragment-packed [8][K_pad/16]...) and b_first (256 f32)."""
+    f = _lib.HeadFusedArgs()
+    t = head_tail_args(srcs[0], 256, B, H, W, [dict(hd, c_base=0) for hd in heads])
+    C.memmove(C.byref(f.tail), C.byref(t), C.sizeof(t))
+    for i, (s, c) in enumerate(zip(srcs, src_strides)):
+        f.src[i], f.src_c[i] = s.data_ptr(), c
+    f.n_src = len(srcs)
+    f.slots, f.K_pad = slots.data_ptr(), k_pad
+    for i, hd in enumerate(heads):
+        f.w_first[i], f.b_first[i] = hd["w_first"].data_ptr(), hd["b_first"].data_ptr()
+    return f
+
+
+def run_head_fused(f):
+    _lib.check(_lib.load().cf_head_fused(C.byref(f), _lib.stream_ptr()), "cf_head_fused")
+
+
 def run_head_tail(a):
     _lib.check(_lib.load().cf_head_tail(C.byref(a), _lib.stream_ptr()), "cf_head_tail")
 

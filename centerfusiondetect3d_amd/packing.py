@@ -94,7 +94,8 @@ def pack_conv(weight, bias, sources: Sequence[Source], stride=1, pad=None, dilat
                       tuple(s.channels for s in sources))
 
 
-def pack_conv_bf16(weight, bias, sources: Sequence[Source], stride=1, pad=None, dilation=1) -> PackedConv:
+def pack_conv_bf16(weight, bias, sources: Sequence[Source], stride=1, pad=None, dilation=1,
+                   fragments=False) -> PackedConv:
     """Packing for cf_conv2d_bf16x3: slots of 8 channels, weights [N_pad][2][K_pad] bf16 with
     w = hi + lo (hi = rne(w), lo = rne(w - hi)).  Source.stride = channels per plane."""
     co, ci, kh, kw = weight.shape
@@ -127,12 +128,16 @@ def pack_conv_bf16(weight, bias, sources: Sequence[Source], stride=1, pad=None, 
     for j, (c0, real, r, q) in enumerate(cols):
         if real:
             w[:co, 8 * j:8 * j + real] = wf[:, c0:c0 + real, r, q]
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
     b = torch.zeros(n_pad)
     b[:co] = bias
-    return PackedConv(torch.stack([hi, lo], dim=1).contiguous(), b, torch.tensor(slots, dtype=torch.int32),
-                      co, n_pad, k_pad, kh, stride, pad, tuple(s.channels for s in sources))
+    if fragments:          # cf_head_fused: A-operand fragment order instead of [N][2][K]
+        wt = pack_fragments(w)
+    else:
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        wt = torch.stack([hi, lo], dim=1).contiguous()
+    return PackedConv(wt, b, torch.tensor(slots, dtype=torch.int32), co, n_pad, k_pad, kh, stride, pad,
+                      tuple(s.channels for s in sources))
 
 
 def pack_fragments(weight2d, n_pad=None):

@@ -121,6 +121,24 @@ typedef struct cf_head_tail_args {
 } cf_head_tail_args;
 int cf_head_tail(const cf_head_tail_args* a, void* stream);
 
+/* cf_head_fused: a whole head group in one launch: 3x3 conv (sources -> 256) + ReLU, then the tail
+ * of cf_head_tail (tail.x / tail.x_stride / tail.c_base are ignored: the hidden tile is produced in
+ * LDS and never written to HBM).  replaces model/networks/detectHeads.py:59-98 end to end.
+ * src[]: split-bf16 NHWC sources (feat [, pc_hm]); slots: 8-channel slots as for cf_conv2d_bf16x3,
+ * K_pad a multiple of 64; w_first[i]: fragment-packed [256/32][K_pad/16] rows of head i in slot
+ * order; b_first[i]: 256 floats. */
+typedef struct cf_head_fused_args {
+  cf_head_tail_args tail;
+  const void* src[2];
+  int32_t src_c[2];
+  int32_t n_src;
+  const cf_slot* slots;
+  int32_t K_pad;
+  const void* w_first[CF_MAX_HEADS];
+  const float* b_first[CF_MAX_HEADS];
+} cf_head_fused_args;
+int cf_head_fused(const cf_head_fused_args* a, void* stream);
+
 /* cf_dcn_v2_fused: modulated deformable 3x3 convolution (stride 1, pad 1, dil 1, groups 1) with
  * the bilinear gather fused into the GEMM A-tile staging, + bias(BN folded) + ReLU.
  * replaces torchvision.ops.deform_conv2d + BN + ReLU of model/networks/dla.py:456-472.

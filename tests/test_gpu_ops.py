@@ -402,3 +402,47 @@ def test_head_tail_fused_chain(dev, n_hidden, B, H, W):
             assert float((got - raw).abs().max()) < tol, float((got - raw).abs().max()) / scale
         if hd["act"] == 3:
             close(hd["out2"], 1.0 / (torch.sigmoid(raw) + 1e-6) - 1.0, 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("n_hidden,radar,B,H,W", [(0, False, 2, 9, 14), (2, True, 1, 16, 20), (1, True, 2, 7, 9)])
+def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W):
+    """3x3 conv (feat [|| pc_hm]) + ReLU -> hidden chain -> output, one launch, vs fp32 torch."""
+    from centerfusiondetect3d_amd import ops, packing
+    n_outs, acts = [10, 1, 3], [2, 3, 0]
+    feat, pch = rnd(B, 64, H, W, seed=1), rnd(B, 3, H, W, seed=2)
+    srcs = [_split(feat, dev)] + ([_split(pch, dev, cs=8)] if radar else [])
+    sources = [packing.Source(64, 64)] + ([packing.Source(3, 8)] if radar else [])
+    xin = torch.cat([feat, pch], 1) if radar else feat
+    ci = xin.shape[1]
+    heads, refs, slots, k_pad = [], [], None, None
+    for i, (no, act) in enumerate(zip(n_outs, acts)):
+        w1, b1 = rnd(256, ci, 3, 3, seed=300 + i, scale=(ci * 9) ** -0.5), rnd(256, seed=310 + i, scale=0.1)
+        x = F.relu(F.conv2d(xin, w1, b1, 1, 1))
+        pc = packing.pack_conv_bf16(w1, b1, sources, fragments=True).to(dev)
+        slots, k_pad = pc.slots, pc.k_pad
+        wh, bh = [], []
+        for l in range(n_hidden):
+            w, b = rnd(256, 256, 1, 1, seed=10 * i + l, scale=1 / 16), rnd(256, seed=50 + 10 * i + l, scale=0.1)
+            x = F.relu(F.conv2d(x, w, b))
+            wh.append(packing.pack_fragments(w.view(256, 256)).to(dev)); bh.append(b.to(dev))
+        w, b = rnd(no, 256, 1, 1, seed=100 + i, scale=1 / 16), rnd(no, seed=200 + i)
+        raw = F.conv2d(x, w, b)
+        b32 = torch.zeros(32); b32[:no] = b
+        out = torch.full((B, no, H, W), float("nan"), device=dev)
+        out2 = torch.full((B, no, H, W), float("nan"), device=dev) if act == 3 else None
+        heads.append(dict(w_first=pc.weight, b_first=pc.bias[:256].contiguous(), w_hidden=wh, b_hidden=bh,
+                          w_out=packing.pack_fragments(w.view(no, 256)).to(dev), b_out=b32.to(dev),
+                          n_out=no, act=act, out=out, out2=out2))
+        refs.append(raw)
+    f = ops.head_fused_args(srcs, [s.shape[-1] for s in srcs], slots, k_pad, B, H, W, heads)
+    ops.run_head_fused(f)
+    for hd, raw in zip(heads, refs):
+        scale = float(raw.abs().max())
+        got = hd["out"].cpu()
+        assert bool(torch.isfinite(got).all())
+        if hd["act"] == 2:
+            close(got, torch.clamp(torch.sigmoid(raw), 1e-4, 1 - 1e-4), 1e-4, 1e-5)
+        else:
+            assert float((got - raw).abs().max()) < 6e-5 * scale * (2 + n_hidden), float((got - raw).abs().max()) / scale
+        if hd["act"] == 3:
+            close(hd["out2"], 1.0 / (torch.sigmoid(raw) + 1e-6) - 1.0, 1e-3, 1e-3)
