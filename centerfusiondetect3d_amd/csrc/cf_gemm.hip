@@ -241,6 +241,113 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvK p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Convolution with <= 16 output channels (stem 7x7 3->16, level0 3x3 16->16 at full resolution):
+// v_mfma_f32_16x16x4_f32 tiles so no MFMA work is spent on padding N to 32.  128 pixels x 16
+// channels per workgroup; each wave owns 32 pixel rows (two 16x16 accumulators of 4 VGPRs).
+// Lane l = (i = l & 15, q = l >> 4) reads 4 consecutive k (one ds_read_b128) of row i and feeds
+// element e to MFMA e, whose 4 k-slots are then {16g + 4q + e | q = 0..3}.
+// ---------------------------------------------------------------------------------------------
+template <bool PRECISE>
+__global__ __launch_bounds__(256) void conv_igemm_n16_kernel(ConvK p) {
+  constexpr int BM = 128, RA = 4;
+  __shared__ __attribute__((aligned(16))) float smem[(BM + 16) * CF_LDS_STRIDE];
+  extern __shared__ __attribute__((aligned(16))) cf_slot lds_slots[];
+  float* As = smem;
+  float* Bs = smem + BM * CF_LDS_STRIDE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM;
+  const int tr = tid >> 3, ts = tid & 7;
+  for (int i = tid; i < p.n_chunks * 8; i += 256) lds_slots[i] = p.slots[i];
+  __syncthreads();
+
+  int y0[RA], x0[RA], boff[RA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int j = 0; j < RA; ++j) {
+    const int m = m0 + tr + 32 * j;
+    if (m < p.ep.M) {
+      const int b = m / HoWo, rem = m - b * HoWo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      y0[j] = ho * p.stride;
+      x0[j] = wo * p.stride;
+      boff[j] = b * p.H * p.W;
+    } else {
+      y0[j] = -(1 << 28);
+      x0[j] = 0;
+      boff[j] = 0;
+    }
+  }
+
+  f32x4 ra[RA], rb;
+  auto load_chunk = [&](int c) {
+    const cf_slot sl = lds_slots[c * 8 + ts];
+    const int src = __builtin_amdgcn_readfirstlane(lds_slots[c * 8].src);
+    const float* sp = src == 1 ? p.src[1] : src == 2 ? p.src[2] : src == 3 ? p.src[3] : p.src[0];
+    const int sc = src == 1 ? p.src_c[1] : src == 2 ? p.src_c[2] : src == 3 ? p.src_c[3] : p.src_c[0];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+      const int y = y0[j] + sl.dy, x = x0[j] + sl.dx;
+      const bool ok = (src >= 0) && (sl.c_off >= 0) && ((unsigned)y < (unsigned)p.H) &&
+                      ((unsigned)x < (unsigned)p.W);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(sp + (size_t)(boff[j] + y * p.W + x) * sc + sl.c_off);
+      ra[j] = v;
+    }
+    if (tid < 128) rb = *reinterpret_cast<const f32x4*>(p.weight + (size_t)tr * p.K_pad + c * CF_BK + ts * 4);
+  };
+
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int i16 = lane & 15, q = lane >> 4;
+  load_chunk(0);
+  for (int c = 0; c < p.n_chunks; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RA; ++j)
+      *reinterpret_cast<f32x4*>(&As[(tr + 32 * j) * CF_LDS_STRIDE + ts * 4]) = ra[j];
+    if (tid < 128) *reinterpret_cast<f32x4*>(&Bs[tr * CF_LDS_STRIDE + ts * 4]) = rb;
+    __syncthreads();
+    if (c + 1 < p.n_chunks) load_chunk(c + 1);
+    f32x4 part[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[i16 * CF_LDS_STRIDE + g * 16 + q * 4]);
+      f32x4 a[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        a[t] = *reinterpret_cast<const f32x4*>(&As[(wave * 32 + t * 16 + i16) * CF_LDS_STRIDE + g * 16 + q * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (PRECISE) part[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][e], b[e], part[t], 0, 0, 0);
+          else acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][e], b[e], acc[t], 0, 0, 0);
+        }
+    }
+    if (PRECISE) {
+      acc[0] += part[0];
+      acc[1] += part[1];
+    }
+  }
+  // C/D layout of the 16x16 tile: col = lane & 15 (channel), row = 4 * (lane >> 4) + reg (pixel)
+  const int n = i16;
+  if (n < p.ep.N) {
+    const float bias = p.ep.bias[n];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wave * 32 + t * 16 + 4 * q + r;
+        if (m < p.ep.M) {
+          float v = acc[t][r] + bias;
+          if (p.ep.residual) v += p.ep.residual[(size_t)m * p.ep.res_stride + n];
+          p.ep.out[(size_t)m * p.ep.out_stride + n] = apply_act(v, p.ep.act);
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // DCNv2 (3x3, stride 1, pad 1): bilinear gather fused into the A-chunk staging
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PRECISE>
@@ -429,6 +536,12 @@ extern "C" int cf_conv2d_fused(const cf_conv_args* a, void* stream) {
   const bool precise = a->precise != 0;
   const size_t dyn_lds = (size_t)(a->K_pad / 4) * sizeof(cf_slot);
   hipStream_t st = (hipStream_t)stream;
+  if (a->N <= 16 && a->out_layout == CF_LAYOUT_NHWC && a->act != CF_ACT_SIGMOID_CLAMP) {
+    const int blocks = (int)((M + 127) / 128);
+    if (precise) launch_dyn(conv_igemm_n16_kernel<true>, blocks, dyn_lds, st, k);
+    else launch_dyn(conv_igemm_n16_kernel<false>, blocks, dyn_lds, st, k);
+    return cf_check_launch("cf_conv2d_fused");
+  }
   // PRECISE doubles the accumulator registers: 64-row tiles keep three workgroups per CU
   DISPATCH_TILE(conv_igemm_kernel, k, precise);
   return cf_check_launch("cf_conv2d_fused");
