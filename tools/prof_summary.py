@@ -1,6 +1,6 @@
 """Summarise a rocprofv3 --kernel-trace CSV: per-kernel totals and the per-launch timeline of the
 LAST forward+decode step (launch order == plan order).
-    python tools/prof_summary.py <kernel_trace.csv> <steps_in_trace> [--timeline]
+    python tools/prof_summary.py <kernel_trace.csv> [--timeline]
 """
 import csv
 import re
@@ -15,14 +15,17 @@ def short(name):
 
 
 def main():
-    path, steps = sys.argv[1], int(sys.argv[2])
+    path = sys.argv[1]
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    per_step = len(rows) // steps
-    last = rows[-per_step:]
+    # a forward starts with the image layout kernel; a step = [marker, next marker)
+    marks = [i for i, r in enumerate(rows) if "nchw_to_nhwc4" in r["Kernel_Name"]]
+    per_step = marks[-1] - marks[-2]
+    last = rows[marks[-2]:marks[-1]]
     span = (int(last[-1]["End_Timestamp"]) - int(last[0]["Start_Timestamp"])) / 1e6
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last) / 1e6
-    print(f"{len(rows)} launches, ~{per_step} per step; last step: span {span:.3f} ms, kernel-busy {busy:.3f} ms")
+    print(f"{len(rows)} launches in the trace, {per_step} per step; one steady-state step: span {span:.3f} ms, "
+          f"kernel-busy {busy:.3f} ms")
     agg = defaultdict(lambda: [0, 0.0])
     for r in last:
         k = short(r["Kernel_Name"])
