@@ -34,6 +34,18 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16 (v_mfma_f32_32x32x16_bf16)
 # dominant kernel = head_fused_kernel: its two launches per step (7 primary heads; 4 secondary heads)
 DOMINANT = ["tails.primary", "tails.secondary"]
+# HBM-side bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+# passes over this same command (FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md §HBM); bench.py cannot
+# run the profiler on itself, so the committed measurement is reported.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_c_pmc_hbm_traffic.json")
+
+
+def measured_traffic(kernel="head_fused_kernel"):
+    try:
+        d = json.load(open(TRAFFIC_FILE))[kernel]
+        return round(d["fetch_bytes_per_launch_x2_corrected"] + d["write_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def synthetic_weights(model, seed=0, offset_std=0.01):
@@ -222,7 +234,7 @@ def main():
             "model_tflops": round(fps * GFLOP_PER_FRAME * (H * W) / (448 * 800) / 1e3, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None,
+                         "traffic": measured_traffic(),
                          "kernel": "head_fused_kernel (2 launches/step: 7 primary heads, 4 secondary heads)",
                          "note": "algorithmic FLOPs (2*MACs); the kernel issues 3 bf16 MFMA passes per MAC "
                                  "(split operands), so MFMA-pipe utilisation is 3x frac",
