@@ -160,3 +160,76 @@ def test_contract_errors(dev):
     m.train()
     with pytest.raises(NotImplementedError):
         m(x, pc_dep=torch.zeros(1, 3, 16, 16, device=dev), calib=torch.zeros(1, 3, 4, device=dev))
+
+
+def test_config_c4_dcn_heavy_offsets(dev):
+    """BASELINE config 4: every IDA node is deformable (the default topology) with offsets raised to
+    O(8 px) so the bilinear gather leaves the 3x3 neighbourhood and crosses image borders."""
+    from centerfusiondetect3d_amd import getModel, centerfusion_middle_config
+    H, W, B = 128, 160, 2
+    sd = model_ref.make_state_dict(radar=True, seed=3, offset_bias_std=8.0)
+    sd["detectHead_0.depth.2.bias"].fill_(-3.0)
+    sd["detectHead_0.dimension.2.bias"].copy_(torch.tensor([1.6, 1.9, 4.4]))
+    sd["detectHead_0.widthHeight.2.bias"].copy_(torch.tensor([9.0, 7.0]))
+    m = getModel(centerfusion_middle_config((H, W)))
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=21, radar=True)
+    with torch.no_grad():
+        ref = model_ref.forward(sd, x, pc_dep=pc_dep, calib=calib)[0]
+        y = m(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))[0]
+    for k in ref:
+        if k != "calib":
+            _assert_maps_close(y[k], ref[k], k)
+    assert np.array_equal((y["pc_hm"] != 0).cpu().numpy(), (ref["pc_hm"] != 0).numpy())
+
+
+def test_config_c5_highres_896x1600(dev):
+    """BASELINE config 5 (nuScenes full resolution, maps 224x400): one frame against the oracle, and
+    at bs=8 the size-independent properties - deterministic, shard == full batch bit for bit."""
+    from centerfusiondetect3d_amd import getModel, centerfusion_middle_config, decode_packed
+    H, W = 896, 1600
+    sd = cases.tuned_state_dict(radar=True, seed=0)
+    m = getModel(centerfusion_middle_config((H, W)))
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    x, pc_dep, calib = cases.model_inputs(8, H, W, seed=31, radar=True, n_points=(100, 200))
+    xd, pd, cd = x.to(dev), pc_dep.to(dev), calib.to(dev)
+    with torch.no_grad():
+        ref = model_ref.forward(sd, x[:1], pc_dep=pc_dep[:1], calib=calib[:1])[0]
+        full = m(xd, pc_dep=pd, calib=cd)
+        one = m(xd[:1].contiguous(), pc_dep=pd[:1].contiguous(), calib=cd[:1].contiguous())
+        again = m(xd, pc_dep=pd, calib=cd)
+    for k, v in ref.items():
+        if k == "calib":
+            continue
+        assert tuple(full[0][k].shape[2:]) == (224, 400)
+        _assert_maps_close(one[0][k], v, k)
+        assert torch.equal(one[0][k], full[0][k][:1]), k
+        assert torch.equal(again[0][k], full[0][k]), k
+    det, _ = decode_packed(full, (224, 400), 100)
+    det1, _ = decode_packed(one, (224, 400), 100)
+    assert torch.equal(det1, det[:1]) and bool(torch.isfinite(det).all())
+
+
+def test_config_c2_full_size_properties(dev):
+    """BASELINE config 2 at its full size (bs=16, 448x800): shards of the batch reproduce the full
+    batch bit for bit (what makes the 8-GPU data-parallel run equal to the single-GPU one), and
+    frame order is respected (a permuted batch gives permuted outputs)."""
+    from centerfusiondetect3d_amd import decode_packed
+    H, W, B = 448, 800, 16
+    m = _model(True, dev, (H, W))
+    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=41, radar=True, n_points=(50, 200))
+    xd, pd, cd = x.to(dev), pc_dep.to(dev), calib.to(dev)
+    with torch.no_grad():
+        full = m(xd, pc_dep=pd, calib=cd)
+        det_full, _ = decode_packed(full, (112, 200), 100)
+        perm = torch.arange(B - 1, -1, -1, device=dev)
+        rev = m(xd[perm].contiguous(), pc_dep=pd[perm].contiguous(), calib=cd[perm].contiguous())
+        det_rev, _ = decode_packed(rev, (112, 200), 100)
+        assert torch.equal(det_rev, det_full[perm])
+        for lo, hi in ((0, 2), (8, 16)):
+            part = m(xd[lo:hi].contiguous(), pc_dep=pd[lo:hi].contiguous(), calib=cd[lo:hi].contiguous())
+            det, _ = decode_packed(part, (112, 200), 100)
+            assert torch.equal(det, det_full[lo:hi])
+    assert int((full[0]["pc_hm"] != 0).sum()) > 0
