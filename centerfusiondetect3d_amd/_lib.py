@@ -74,6 +74,7 @@ SYMBOLS = {
     "cf_frustum_assoc": (_i, [_f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, C.c_float, _f, _f, _f, _f]),
     "cf_pillar_expand": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _i, _i, _d, _d, _d, _f, _f, _f, _f]),
     "cf_decode_gather": (_i, [C.POINTER(DecodeArgs), _f]),
+    "cf_post_process": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _f]),
     "cf_last_error": (C.c_char_p, []),
     "cf_abi_version": (_i, []),
 }

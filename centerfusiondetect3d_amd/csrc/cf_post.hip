@@ -428,6 +428,74 @@ __global__ void decode_gather_kernel(cf_decode_args a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// 2D -> 3D post-processing of decoded detections (utils/postProcess.py:13-85), one thread per row.
+// in : det (B,K,33) [score, cls, cxn, cyn, x1, y1, x2, y2, rot8, dim3, amodal2, att8, vel3, depth]
+// out: (B,K,54) [score, cls+1, cx, cy, x1, y1, x2, y2, depth, alpha, dim3, amodal2, att8, vel3,
+//                loc3, yaw, box3d 8x3]
+// ---------------------------------------------------------------------------------------------
+__global__ void post_process_kernel(const float* __restrict__ det, const float* __restrict__ calib,
+                                    const float* __restrict__ tinv, int B, int K, float out_w, float out_h,
+                                    float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * K) return;
+  const float* d = det + (size_t)t * 33;
+  const float* cal = calib + (size_t)(t / K) * 12;
+  float* o = out + (size_t)t * 54;
+  const float t00 = tinv[0], t01 = tinv[1], t02 = tinv[2], t10 = tinv[3], t11 = tinv[4], t12 = tinv[5];
+  auto ax = [&](float x, float y) { return (t00 * x + t01 * y) + t02; };
+  auto ay = [&](float x, float y) { return (t10 * x + t11 * y) + t12; };
+  o[0] = d[0];
+  o[1] = d[1] + 1.0f;
+  // 2D boxes back to the source image
+  o[4] = ax(d[4], d[5]); o[5] = ay(d[4], d[5]);
+  o[6] = ax(d[6], d[7]); o[7] = ay(d[6], d[7]);
+  const float depth = d[32];
+  o[8] = depth;
+  // observation angle (pointcloud.py:207-210)
+  const float* r = d + 8;
+  const float idx = r[1] > r[5] ? 1.0f : 0.0f;
+  const float a1 = atan2f(r[2], r[3]) + (float)(-0.5 * M_PI);
+  const float a2 = atan2f(r[6], r[7]) + (float)(0.5 * M_PI);
+  const float alpha = a1 * idx + a2 * (1.0f - idx);
+  o[9] = alpha;
+  const float dh = d[16], dw = d[17], dl = d[18];
+  o[10] = dh; o[11] = dw; o[12] = dl;
+  o[13] = d[19]; o[14] = d[20];
+  for (int i = 0; i < 8; ++i) o[15 + i] = d[21 + i];
+  // centre = affine(normalised centre * (W,H) + amodal offset)
+  const float px = d[2] * out_w + d[19], py = d[3] * out_h + d[20];
+  const float cx = ax(px, py), cy = ay(px, py);
+  o[2] = cx; o[3] = cy;
+  // unproject (ddd.py:143-166) and yaw (ddd.py:122-140)
+  const float z = depth - cal[11];
+  const float X = ((cx * depth - cal[3]) - cal[2] * z) / cal[0];
+  const float Y = ((cy * depth - cal[7]) - cal[6] * z) / cal[5] + dh / 2.0f;
+  float yaw = alpha + atan2f(cx - cal[2], cal[0]);
+  const float PI_F = (float)M_PI, TWO_PI_F = (float)(2.0 * M_PI);
+  if (yaw > PI_F) yaw -= TWO_PI_F;
+  if (yaw < -PI_F) yaw += TWO_PI_F;
+  o[26] = X; o[27] = Y; o[28] = z;
+  o[29] = yaw;
+  // velocity re-projected on the heading
+  const float cs = cosf(yaw), sn = sinf(yaw);
+  const float V = sqrtf(d[29] * d[29] + d[31] * d[31]);
+  o[23] = cs * V; o[24] = d[30]; o[25] = -sn * V;
+  // 3D box corners (pointcloud.py:239-296 + ddd.py:8-23); zero if any dimension <= 0
+  const bool bad = dh <= 0.0f || dw <= 0.0f || dl <= 0.0f;
+  const float hx = 0.5f * dl, hz = 0.5f * dw;
+  const float sx[4] = {hx, hx, -hx, -hx}, sz[4] = {hz, -hz, -hz, hz};
+  for (int q = 0; q < 8; ++q) {
+    const float xc = sx[q & 3], yc = q < 4 ? 0.0f : -dh, zc = sz[q & 3];
+    const float bx = ((cs * xc + 0.0f * yc) + sn * zc) + X;
+    const float by = ((0.0f * xc + 1.0f * yc) + 0.0f * zc) + Y;
+    const float bz = (((-sn) * xc + 0.0f * yc) + cs * zc) + z;
+    o[30 + q * 3 + 0] = bad ? 0.0f : bx;
+    o[30 + q * 3 + 1] = bad ? 0.0f : by;
+    o[30 + q * 3 + 2] = bad ? 0.0f : bz;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pillar expansion (dataset/generic_dataset.py:738-942, datasets/nuscenes.py:221-263), fp64
 // ---------------------------------------------------------------------------------------------
 constexpr int PL_THREADS = 256;
@@ -587,6 +655,16 @@ extern "C" int cf_decode_gather(const cf_decode_args* a, void* stream) {
   const int n = a->B * a->K;
   hipLaunchKernelGGL(decode_gather_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, *a);
   return cf_check_launch("cf_decode_gather");
+}
+
+extern "C" int cf_post_process(const float* det, const float* calib, const float* trans_inv, int B, int K,
+                               int out_h, int out_w, float* out, void* stream) {
+  CF_REQUIRE(det && calib && trans_inv && out, "cf_post_process: null buffer");
+  CF_REQUIRE(B > 0 && K > 0 && out_h > 0 && out_w > 0, "cf_post_process: bad geometry");
+  const int n = B * K;
+  hipLaunchKernelGGL(post_process_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, det, calib,
+                     trans_inv, B, K, (float)out_w, (float)out_h, out);
+  return cf_check_launch("cf_post_process");
 }
 
 extern "C" int cf_pillar_expand(const double* pc_2d, const double* pc_3d, const int32_t* counts, int B,

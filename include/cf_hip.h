@@ -226,6 +226,16 @@ typedef struct cf_decode_args {
 } cf_decode_args;
 int cf_decode_gather(const cf_decode_args* a, void* stream);
 
+/* cf_post_process: 2D -> 3D post-processing of decoded detections, replaces utils/postProcess.py:13-85
+ * (+ utils/ddd.py:8-23,122-199, utils/pointcloud.py:195-296) for the inference case.
+ * det (B,K,33) as written by cf_decode_gather; calib (B,3,4) f32; trans_inv (2,3) f32 device = the
+ * output-map -> source-image affine (getAffineTransform(..., inverse=True)); out (B,K,54) f32:
+ * [score, classId+1, centre xy (source px), bbox x1 y1 x2 y2 (source px), depth, alpha, dim hwl,
+ *  amodal_offset xy, nuscenes_att 8, velocity 3 (re-projected on the heading), location xyz, yaw,
+ *  8 box corners xyz (all zero when a dimension is <= 0)]. */
+int cf_post_process(const float* det, const float* calib, const float* trans_inv, int B, int K,
+                    int out_h, int out_w, float* out, void* stream);
+
 const char* cf_last_error(void);
 int cf_abi_version(void);
 

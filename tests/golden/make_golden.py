@@ -8,7 +8,9 @@ Import recipe = SURVEY.md Appendix D: packages the reference imports but that ar
 this image (nuscenes-devkit, pyquaternion, lightning, yacs, torchvision) are registered as
 inert module objects before the import; `torchvision.ops.deform_conv2d` is served by
 oracle/dcn_ref.py (so the DCN arithmetic itself stays "parity unpinned" - it is held by the
-known-answer tests - while everything around it is the reference's own code).
+known-answer tests - while everything around it is the reference's own code).  For utils/postProcess.py
+the absent `cv2` is a module object whose only attribute is a numpy 3-point solve standing for
+cv2.getAffineTransform (so that solve is likewise outside the pin).
 
     python tests/golden/make_golden.py
 """
@@ -58,6 +60,11 @@ def _install_inert_modules():
     mod("lightning.pytorch.utilities", rank_zero_only=lambda f: f)
     mod("yacs"); mod("yacs.config", CfgNode=CfgNode)
     mod("torchvision"); mod("torchvision.ops", deform_conv2d=dcn_ref.deform_conv2d)
+
+    def get_affine_transform(src, dst):      # cv2.getAffineTransform: exact 3-point solve, float64 (2,3)
+        A = np.concatenate([np.asarray(src, np.float64), np.ones((3, 1))], axis=1)
+        return np.linalg.solve(A, np.asarray(dst, np.float64)).T.copy()
+    mod("cv2", getAffineTransform=get_affine_transform)
 
 
 def reference_config(radar, H, W):
@@ -182,6 +189,20 @@ def main():
     det = fusionDecode([{k: v.clone() for k, v in out.items()}], outputSize=(112, 200), K=100,
                        norm2d=True)
     save("decode_2_norm2d.npz", **{k: v for k, v in det.items()})
+    # ---- 5. postProcess (2D -> 3D) on decoded detections --------------------------------------
+    from utils.postProcess import postProcess
+    for seed in (0, 1):
+        out = cases.decode_case(seed, radar=True)
+        out["depth2"] = out["depth2"].abs() * 20 + 2          # plausible positive depths
+        out["dimension"] = out["dimension"].abs() + 0.1
+        if seed == 1:
+            out["dimension"][:, 1] -= 0.6                     # some non-positive dims -> zeroed boxes
+        det = fusionDecode([{k: v.clone() for k, v in out.items()}], outputSize=(112, 200), K=100)
+        calibs = cases.model_inputs(2, 448, 800, seed=0)[2]
+        pp = postProcess({k: v.clone() for k, v in det.items()}, np.array([800.0, 450.0], np.float32), 1600.0,
+                         112, 200, calibs)
+        save(f"postprocess_{seed}.npz", **{k: v for k, v in pp.items()})
+
     # tie-heavy: only the strictly-distinct prefix and the selected *set* are well defined
     out = cases.decode_case(3, radar=True, tie_heavy=True)
     heat = ref_nms(out["heatmap"])

@@ -446,3 +446,25 @@ def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W):
             assert float((got - raw).abs().max()) < 6e-5 * scale * (2 + n_hidden), float((got - raw).abs().max()) / scale
         if hd["act"] == 3:
             close(hd["out2"], 1.0 / (torch.sigmoid(raw) + 1e-6) - 1.0, 1e-3, 1e-3)
+
+
+# ----------------------------------------------------------------------------------- postProcess
+@pytest.mark.parametrize("seed", [0, 1])
+def test_post_process_vs_reference_golden(dev, golden_dir, seed):
+    from centerfusiondetect3d_amd import fusionDecode, postProcess
+    from tests.test_oracle_golden import postprocess_inputs
+    g = np.load(os.path.join(golden_dir, f"postprocess_{seed}.npz"))
+    out, calibs = postprocess_inputs(seed)
+    det = fusionDecode([{k: v.to(dev) for k, v in out.items()}], outputSize=(112, 200), K=100)
+    pp = postProcess(det, np.array([800.0, 450.0], np.float32), 1600.0, 112, 200, calibs.to(dev))
+    assert set(pp.keys()) == set(g.files)
+    for k in g.files:
+        got, ref = pp[k].cpu().numpy(), g[k]
+        assert got.shape == ref.shape, k
+        if k in ("scores", "classIds", "dimension", "amodal_offset", "nuscenes_att", "depth"):
+            assert np.array_equal(got, ref), k                         # pass-through fields: exact
+        else:                                                          # trig / affine arithmetic
+            np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-4, err_msg=k)
+    if seed == 1:
+        bad = (g["dimension"] <= 0).any(-1)
+        assert bad.any() and not pp["bboxes3d"].cpu().numpy()[bad].any()

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import model_ref, frustum_ref, decode_ref
+from oracle import model_ref, frustum_ref, decode_ref, postprocess_ref
 from tests.golden import cases
 
 
@@ -117,3 +117,26 @@ def test_decode_ties_as_sets(golden_dir):
         tie = ~distinct
         key = cls[b][tie].astype(np.int64) * (112 * 200) + inds[b][tie]
         assert np.all(np.diff(key) > 0)
+
+
+def postprocess_inputs(seed):
+    out = cases.decode_case(seed, radar=True)
+    out["depth2"] = out["depth2"].abs() * 20 + 2
+    out["dimension"] = out["dimension"].abs() + 0.1
+    if seed == 1:
+        out["dimension"][:, 1] -= 0.6
+    return out, cases.model_inputs(2, 448, 800, seed=0)[2]
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_postprocess_matches_reference(golden_dir, seed):
+    g = _load(golden_dir, f"postprocess_{seed}.npz")
+    out, calibs = postprocess_inputs(seed)
+    det = decode_ref.fusion_decode([out], (112, 200), 100)
+    pp = postprocess_ref.post_process(det, (800.0, 450.0), 1600.0, 112, 200, calibs)
+    assert set(pp.keys()) == set(g.files)
+    for k in g.files:
+        assert np.array_equal(pp[k].numpy(), g[k]), k
+    if seed == 1:                       # boxes with a non-positive dimension are zeroed
+        bad = (g["dimension"] <= 0).any(-1)
+        assert bad.any() and not g["bboxes3d"][bad].any()
