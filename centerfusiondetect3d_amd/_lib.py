@@ -20,7 +20,7 @@ class ConvArgs(C.Structure):
                 ("bias", _f), ("K_pad", C.c_int32), ("N", C.c_int32), ("N_pad", C.c_int32),
                 ("residual", _f), ("res_stride", C.c_int32), ("out", _f), ("out2", _f),
                 ("out_stride", C.c_int32), ("out_layout", C.c_int32), ("act", C.c_int32),
-                ("precise", C.c_int32)]
+                ("precise", C.c_int32), ("out_scale", C.c_float)]
 
 
 class DcnArgs(C.Structure):
@@ -61,6 +61,7 @@ _i, _d = C.c_int, C.c_double
 SYMBOLS = {
     "cf_conv2d_fused": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_conv2d_bf16x3": (_i, [C.POINTER(ConvArgs), _f]),
+    "cf_conv2d_f16x3": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_split_bf16": (_i, [_f, _f, C.c_long, _i, _i, _i, _f]),
     "cf_head_tail": (_i, [C.POINTER(HeadTailArgs), _f]),
     "cf_head_fused": (_i, [C.POINTER(HeadFusedArgs), _f]),

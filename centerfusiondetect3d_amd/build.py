@@ -22,6 +22,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"
 SOURCES = [
     ("cf_gemm.hip", []),
     ("cf_gemm_bf16.hip", []),
+    ("cf_gemm_f16.hip", []),
     ("cf_heads.hip", []),
     ("cf_elementwise.hip", []),
     ("cf_post.hip", ["-ffp-contract=off"]),

@@ -1,0 +1,292 @@
+// Implicit-GEMM convolution with fp32 STORAGE and split-fp16 COMPUTE ("f16x3") on the gfx950 f16 MFMA
+// pipe - the fast path for the backbone / offset convolutions, whose rounding must stay at fp32 level
+// because the DCN neck amplifies it ~100x (DESIGN.md §4 Numerics).
+//
+// Numerics.  An fp32 operand x (times a power-of-two scale that keeps its low part out of the fp16
+// subnormal range) is split into hi = rne_f16(x), lo = rne_f16(x - hi): hi + lo carries ~22-24
+// significant bits.  A product is  a_hi*b_hi + (a_lo*b_hi + a_hi*b_lo)  - three
+// v_mfma_f32_32x32x16_f16 per 16-deep k-step (the dropped a_lo*b_lo term is < 2^-22 relative).  Each
+// MFMA sums its 16 products before ONE fp32 rounding into the accumulator, so the rounding chain is
+// K/16 long instead of K (fp32 MFMA 32x32x2: K/2); the two small cross terms go to their own
+// accumulator so they do not add rounding steps to the main sum.  CPU emulation and the measured
+// end-to-end error put this at the level of the two-level fp32 path (tools/stage_error.py).
+// Scales: weights are pre-multiplied by 2^s per layer (host, max|w| -> ~2^14), activations by 2^4 at
+// staging; the epilogue multiplies by 2^-(s+4) - all exact.  Activations must satisfy |x| < 4094
+// (fp16 range after the 2^4 scale); they are clamped there, which only matters for absurd inputs.
+//
+// Structure (same SWAPPED orientation as cf_heads.hip): MFMA A-operand = weights, pre-packed on the
+// host in fragment order and read straight from L2 (2 k-steps ahead in registers, no LDS, no
+// barrier); B-operand = pixels: the fp32 NHWC activations are gathered per 8-channel slot, split to
+// fp16 hi/lo on the fly and staged through a double-buffered LDS tile [64*WP px][32 k] - one barrier
+// per 32-deep chunk.  Workgroup = 4 waves as WC (channel groups) x WP (pixel groups); a wave owns
+// RT*32 output channels x 64 pixels.  Accumulators have pixels on lanes and 4 consecutive channels
+// per register group, so the fp32 NHWC store is one 16-byte write per lane and group.
+#include "cf_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float ASCALE = 16.0f;   // activation pre-scale (2^4), undone by out_scale
+constexpr int FROWB = 80;         // LDS bytes per pixel row per plane: 32 f16 + 16 B pad
+
+struct ConvF {
+  const float* src[CF_MAX_SRC];
+  int src_c[CF_MAX_SRC];
+  const unsigned char* weight;  // [N_pad/32][K_pad/16][2][64][8 f16]
+  const cf_slot* slots;         // 8-channel slots, 4 per chunk
+  const float* bias;
+  const float* residual;
+  float* out;
+  int H, W, Ho, Wo, stride, n_chunks, res_stride, out_stride, act, M, N, HoWo, n_rt;
+  float out_scale;
+};
+
+__device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
+  return ((unsigned)__builtin_bit_cast(unsigned short, b) << 16) | __builtin_bit_cast(unsigned short, a);
+}
+
+// 8 fp32 -> scaled, clamped, split into fp16 hi / lo (4 dwords each)
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4& hi, u32x4& lo) {
+  _Float16 h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float x = (e < 4 ? v0[e] : v1[e - 4]) * ASCALE;
+    x = fminf(fmaxf(x, -65504.0f), 65504.0f);
+    h[e] = (_Float16)x;
+    l[e] = (_Float16)(x - (float)h[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = pack_h2(h[2 * e], h[2 * e + 1]);
+    lo[e] = pack_h2(l[2 * e], l[2 * e + 1]);
+  }
+}
+
+__device__ __forceinline__ const f16x8* wfrag16(const unsigned char* w, int rt, int ks, int plane, int n_ks, int lane) {
+  return reinterpret_cast<const f16x8*>(w + ((((size_t)rt * n_ks + ks) * 2 + plane) * 64 + lane) * 16);
+}
+
+// DB: double-buffered pixel tile (one barrier per chunk).  The 256-pixel tile of the 64-channel
+// layers (WP = 4) is single-buffered (two barriers per chunk) so two workgroups still fit a CU.
+template <int WC, int WP, int RT, bool DB>
+__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvF p) {
+  static_assert(WC * WP == 4, "4 waves per workgroup");
+  constexpr int PXB = 64 * WP;             // pixels per workgroup
+  constexpr int PLANE = PXB * FROWB;       // bytes per plane of one chunk buffer
+  constexpr int BUF = 2 * PLANE;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(DB ? 2 : 1) * BUF];
+  extern __shared__ __attribute__((aligned(16))) cf_slot lds_slots[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wc = wave / WP, wp = wave % WP;
+  const int m0 = blockIdx.x * PXB;
+  const int rt0 = (blockIdx.y * WC + wc) * RT;          // first 32-row tile of this wave
+  const bool w_ok = rt0 < p.n_rt;                       // (RT divides the padded tile count)
+  const int n_ks = p.n_chunks * 2;
+  for (int i = tid; i < p.n_chunks * 4; i += 256) lds_slots[i] = p.slots[i];
+
+  // staging role: WP (pixel, 8-channel unit) pairs per thread
+  int y0[WP], x0[WP], boff[WP];
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int px = (tid + 256 * i) >> 2;
+    const int m = m0 + px;
+    if (m < p.M) {
+      const int b = m / p.HoWo, rem = m - b * p.HoWo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      y0[i] = ho * p.stride;
+      x0[i] = wo * p.stride;
+      boff[i] = b * p.H * p.W;
+    } else {
+      y0[i] = -(1 << 28);
+      x0[i] = 0;
+      boff[i] = 0;
+    }
+  }
+  __syncthreads();
+
+  f32x4 raw[WP][2];
+  auto load_b = [&](int c) {
+    const int src = __builtin_amdgcn_readfirstlane(lds_slots[c * 4].src);
+    const float* sp = src == 1 ? p.src[1] : src == 2 ? p.src[2] : src == 3 ? p.src[3] : p.src[0];
+    const int sc = src == 1 ? p.src_c[1] : src == 2 ? p.src_c[2] : src == 3 ? p.src_c[3] : p.src_c[0];
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const cf_slot s = lds_slots[c * 4 + (tid & 3)];
+      const int y = y0[i] + s.dy, x = x0[i] + s.dx;
+      const bool ok = (s.c_off >= 0) && ((unsigned)y < (unsigned)p.H) && ((unsigned)x < (unsigned)p.W);
+      raw[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      raw[i][1] = raw[i][0];
+      if (ok) {
+        const float* a = sp + (size_t)(boff[i] + y * p.W + x) * sc + s.c_off;
+        raw[i][0] = *reinterpret_cast<const f32x4*>(a);
+        raw[i][1] = *reinterpret_cast<const f32x4*>(a + 4);
+      }
+    }
+  };
+  auto store_b = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const int pr = tid + 256 * i;
+      u32x4 hi, lo;
+      split8(raw[i][0], raw[i][1], hi, lo);
+      unsigned char* o = buf + (pr >> 2) * FROWB + (pr & 3) * 16;
+      *reinterpret_cast<u32x4*>(o) = hi;
+      *reinterpret_cast<u32x4*>(o + PLANE) = lo;
+    }
+  };
+
+  f32x16 accm[RT][2], accs[RT][2];   // main (hi*hi) and small (lo*hi + hi*lo) sums
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        accm[a][b][r] = 0.0f;
+        accs[a][b][r] = 0.0f;
+      }
+
+  f16x8 wh[2][RT], wl[2][RT];        // weight fragments of k-steps (2n) and (2n+1)
+  auto load_w = [&](f16x8 (&dh)[RT], f16x8 (&dl)[RT], int ks) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      dh[rt] = *wfrag16(p.weight, w_ok ? rt0 + rt : 0, ks, 0, n_ks, lane);
+      dl[rt] = *wfrag16(p.weight, w_ok ? rt0 + rt : 0, ks, 1, n_ks, lane);
+    }
+  };
+  auto mma_kstep = [&](const unsigned char* buf, int s, const f16x8 (&ah)[RT], const f16x8 (&al)[RT]) {
+    f16x8 xh[2], xl[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const unsigned char* row = buf + (wp * 64 + ct * 32 + li) * FROWB + s * 32 + h * 16;
+      xh[ct] = *reinterpret_cast<const f16x8*>(row);
+      xl[ct] = *reinterpret_cast<const f16x8*>(row + PLANE);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rt], xh[ct], accs[rt][ct], 0, 0, 0);
+        accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rt], xl[ct], accs[rt][ct], 0, 0, 0);
+        accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rt], xh[ct], accm[rt][ct], 0, 0, 0);
+      }
+  };
+
+  load_b(0);
+  load_w(wh[0], wl[0], 0);
+  load_w(wh[1], wl[1], 1);
+  store_b(smem);
+  if (p.n_chunks > 1) load_b(1);
+  __syncthreads();
+  for (int c = 0; c < p.n_chunks; ++c) {
+    unsigned char* cur = smem + (DB ? (c & 1) * BUF : 0);
+    unsigned char* nxt = smem + (DB ? ((c + 1) & 1) * BUF : 0);
+    mma_kstep(cur, 0, wh[0], wl[0]);
+    if (c + 1 < p.n_chunks) load_w(wh[0], wl[0], 2 * c + 2);
+    mma_kstep(cur, 1, wh[1], wl[1]);
+    if (!DB) __syncthreads();               // single buffer: everyone is done reading it
+    if (c + 1 < p.n_chunks) {
+      load_w(wh[1], wl[1], 2 * c + 3);
+      store_b(nxt);                         // chunk c+1 (requested one chunk ago)
+      if (c + 2 < p.n_chunks) load_b(c + 2);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane = pixel, register group g = 4 consecutive channels
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int m = m0 + wp * 64 + ct * 32 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = (rt0 + rt) * 32 + 8 * g + 4 * h;
+        if (n >= p.N) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
+        if (n + 3 < p.N) {
+          v += *reinterpret_cast<const f32x4*>(p.bias + n);
+          if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.res_stride + n);
+          if (p.act == CF_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+          }
+          *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.out_stride + n) = v;
+        } else {
+          for (int e = 0; e < 4 && n + e < p.N; ++e) {
+            float x = v[e] + p.bias[n + e];
+            if (p.residual) x += p.residual[(size_t)m * p.res_stride + n + e];
+            if (p.act == CF_ACT_RELU) x = fmaxf(x, 0.0f);
+            p.out[(size_t)m * p.out_stride + n + e] = x;
+          }
+        }
+      }
+  }
+}
+
+template <typename K>
+void launch_f16(K kernel, dim3 grid, size_t dyn, hipStream_t st, const ConvF& args) {
+  static size_t limit = 0;
+  if (dyn > limit) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(dyn < 16384 ? 16384 : dyn));
+    limit = dyn < 16384 ? 16384 : dyn;
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(256), dyn, st, args);
+}
+
+}  // namespace
+
+extern "C" int cf_conv2d_f16x3(const cf_conv_args* a, void* stream) {
+  CF_REQUIRE(a != nullptr, "cf_conv2d_f16x3: null args");
+  CF_REQUIRE(a->n_src >= 1 && a->n_src <= CF_MAX_SRC, "cf_conv2d_f16x3: n_src=%d", a->n_src);
+  CF_REQUIRE(a->K_pad > 0 && a->K_pad % 32 == 0, "cf_conv2d_f16x3: K_pad=%d not a multiple of 32", a->K_pad);
+  CF_REQUIRE(a->N > 0 && a->N_pad >= a->N && a->N_pad % 32 == 0, "cf_conv2d_f16x3: N=%d N_pad=%d", a->N, a->N_pad);
+  CF_REQUIRE(a->N_pad == 32 || a->N_pad % 64 == 0, "cf_conv2d_f16x3: N_pad=%d must be 32 or a multiple of 64", a->N_pad);
+  CF_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Ho > 0 && a->Wo > 0 && a->stride > 0, "cf_conv2d_f16x3: bad geometry");
+  CF_REQUIRE(a->weight && a->slots && a->bias && a->out, "cf_conv2d_f16x3: null buffer");
+  CF_REQUIRE(a->out_layout == CF_LAYOUT_NHWC && a->out_stride >= a->N && a->out_stride % 4 == 0,
+             "cf_conv2d_f16x3: output must be fp32 NHWC with a stride that is a multiple of 4");
+  CF_REQUIRE(a->act == CF_ACT_NONE || a->act == CF_ACT_RELU, "cf_conv2d_f16x3: act=%d unsupported", a->act);
+  CF_REQUIRE(a->out_scale > 0.0f, "cf_conv2d_f16x3: out_scale must be the 2^-(s+4) the weights were packed with");
+  CF_REQUIRE(!a->residual || a->res_stride % 4 == 0, "cf_conv2d_f16x3: residual stride must be a multiple of 4");
+  for (int i = 0; i < a->n_src; ++i)
+    CF_REQUIRE(a->src[i] && a->src_c[i] > 0 && a->src_c[i] % 8 == 0, "cf_conv2d_f16x3: source %d invalid", i);
+  const long M = (long)a->B * a->Ho * a->Wo;
+  CF_REQUIRE((long)a->B * a->H * a->W < (1L << 30) && M < (1L << 31), "cf_conv2d_f16x3: tensor too large");
+  ConvF k{};
+  for (int i = 0; i < CF_MAX_SRC; ++i) {
+    k.src[i] = i < a->n_src ? a->src[i] : nullptr;
+    k.src_c[i] = i < a->n_src ? a->src_c[i] : 0;
+  }
+  k.weight = reinterpret_cast<const unsigned char*>(a->weight);
+  k.slots = a->slots;
+  k.bias = a->bias;
+  k.residual = a->residual;
+  k.out = a->out;
+  k.H = a->H; k.W = a->W; k.Ho = a->Ho; k.Wo = a->Wo; k.stride = a->stride;
+  k.n_chunks = a->K_pad / 32;
+  k.res_stride = a->res_stride; k.out_stride = a->out_stride; k.act = a->act;
+  k.M = (int)M; k.N = a->N; k.HoWo = a->Ho * a->Wo;
+  k.n_rt = a->N_pad / 32;
+  k.out_scale = a->out_scale;
+  const size_t dyn = (size_t)k.n_chunks * 4 * sizeof(cf_slot);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->N_pad == 32) {
+    launch_f16(conv_f16x3_kernel<1, 4, 1, false>, dim3((unsigned)((M + 255) / 256), 1), dyn, st, k);
+  } else if (a->N_pad == 64) {
+    launch_f16(conv_f16x3_kernel<1, 4, 2, false>, dim3((unsigned)((M + 255) / 256), 1), dyn, st, k);
+  } else if (a->N_pad == 128) {
+    launch_f16(conv_f16x3_kernel<2, 2, 2, true>, dim3((unsigned)((M + 127) / 128), 1), dyn, st, k);
+  } else {
+    launch_f16(conv_f16x3_kernel<4, 1, 2, true>, dim3((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 255) / 256)), dyn, st, k);
+  }
+  return cf_check_launch("cf_conv2d_f16x3");
+}

@@ -192,7 +192,8 @@ class _Plan:
             self.step_index[name] = len(self.steps)
             self.step_flops[name] = 2.0 * B * ho * wo * pc.n * (pc.kh * pc.kh * sum(
                 int(c) for c in pc.real_cin))
-            self.steps.append((self.lib.cf_conv2d_fused, C.byref(a)))
+            fn = self.lib.cf_conv2d_f16x3 if pc.out_scale > 0 else self.lib.cf_conv2d_fused
+            self.steps.append((fn, C.byref(a)))
             return out, a
 
         def pool(x):
@@ -486,6 +487,7 @@ class DLASeg(nn.Module):
         self._packed = None
         self._plans = {}
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
+        self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
         self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)
         self.heads_fused = True  # with heads_bf16: one launch per head group, hidden maps stay in LDS
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
@@ -508,9 +510,19 @@ class DLASeg(nn.Module):
         def bn(p):
             return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"])
 
+        f16 = bool(self.conv_f16)
+
+        def pack_any(w, b, sources, stride=1):
+            """split-fp16 products (fp32 storage) wherever the sources allow 8-channel slots."""
+            # (<= 32 output channels stay on the fp32 kernels: a 32-row MFMA tile per wave leaves the
+            #  f16 path bound by the on-the-fly operand split)
+            if f16 and w.shape[0] > 32 and all(s.stride % 8 == 0 and s.channels % 8 == 0 for s in sources):
+                return packing.pack_conv_f16(w, b, sources, stride=stride).to(device)
+            return packing.pack_conv(w, b, sources, stride=stride).to(device)
+
         def conv_bn(name, wkey, bnkey, sources, stride=1, bias=None):
             w, b = packing.fold_bn(sd[wkey], bias, bn(bnkey) if bnkey else None)
-            pk[name] = packing.pack_conv(w, b, sources, stride=stride).to(device)
+            pk[name] = pack_any(w, b, sources, stride=stride)
 
         conv_bn("base.base_layer", "base.base_layer.0.weight", "base.base_layer.1", [Source(3, 4)])
         conv_bn("base.level0", "base.level0.0.weight", "base.level0.1", [Source(16, 16)])
@@ -535,9 +547,9 @@ class DLASeg(nn.Module):
         def dcn(p, ci, co):
             w, b = packing.fold_bn(sd[p + ".weight"], sd[p + ".bias"], bn(p + ".activation.0"))
             pk[p] = packing.pack_dcn(w, b).to(device)
-            pk[p + ".conv_offset_mask"] = packing.pack_conv(
+            pk[p + ".conv_offset_mask"] = pack_any(
                 sd[p + ".conv_offset_mask.weight"].float().cpu(),
-                sd[p + ".conv_offset_mask.bias"].float().cpu(), [Source(ci, ci)]).to(device)
+                sd[p + ".conv_offset_mask.bias"].float().cpu(), [Source(ci, ci)])
 
         def ida(p, o, srcs, fs):
             for n in range(1, len(srcs)):

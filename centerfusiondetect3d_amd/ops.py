@@ -42,7 +42,25 @@ def conv_args(pc: PackedConv, srcs: Sequence[torch.Tensor], src_strides: Sequenc
     a.out2 = _lib.ptr(out2)
     a.out_stride, a.out_layout, a.act = out_stride, layout, act
     a.precise = int(bool(precise))
+    a.out_scale = float(getattr(pc, "out_scale", 0.0))
     return a
+
+
+def run_conv_f16(a: _lib.ConvArgs):
+    _lib.check(_lib.load().cf_conv2d_f16x3(C.byref(a), _lib.stream_ptr()), "cf_conv2d_f16x3")
+
+
+def conv2d_f16x3(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, residual=None, out=None):
+    """fp32 NHWC in / out, split-fp16 products (packing.pack_conv_f16)."""
+    _need_cuda(*srcs, residual)
+    Ho = (H + 2 * pc.pad - pc.kh) // pc.stride + 1
+    Wo = (W + 2 * pc.pad - pc.kh) // pc.stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, pc.n), device=srcs[0].device, dtype=torch.float32)
+    a = conv_args(pc, srcs, [s.shape[-1] for s in srcs], B, H, W, out, out.shape[-1], act, residual,
+                  residual.shape[-1] if residual is not None else 0, LAYOUT_NHWC, None, 0, False)
+    run_conv_f16(a)
+    return out
 
 
 def run_conv(a: _lib.ConvArgs):

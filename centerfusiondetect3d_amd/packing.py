@@ -49,6 +49,7 @@ class PackedConv:
     stride: int
     pad: int
     real_cin: tuple = ()      # real input channels per source (for FLOP accounting)
+    out_scale: float = 0.0    # cf_conv2d_f16x3: 2^-(s+4)
 
     def to(self, device):
         self.weight = self.weight.to(device).contiguous()
@@ -138,6 +139,50 @@ def pack_conv_bf16(weight, bias, sources: Sequence[Source], stride=1, pad=None, 
         wt = torch.stack([hi, lo], dim=1).contiguous()
     return PackedConv(wt, b, torch.tensor(slots, dtype=torch.int32), co, n_pad, k_pad, kh, stride, pad,
                       tuple(s.channels for s in sources))
+
+
+def pack_conv_f16(weight, bias, sources: Sequence[Source], stride=1, pad=None, dilation=1) -> PackedConv:
+    """Packing for cf_conv2d_f16x3: fp32 NHWC sources, 8-channel slots (4 per 32-deep chunk), weights
+    scaled by 2^s (max|w| -> [2^13, 2^14)), split into fp16 hi/lo and laid out in MFMA A-operand
+    fragment order.  PackedConv.out_scale = 2^-(s+4) undoes the weight and activation scales."""
+    co, ci, kh, kw = weight.shape
+    assert ci == sum(s.channels for s in sources), (ci, [s.channels for s in sources])
+    pad = (kh - 1) // 2 * dilation if pad is None else pad
+    n_pad = 32 if co <= 32 else ((co + 63) // 64) * 64
+    slots, cols, c_lo = [], [], 0
+    for si, s in enumerate(sources):
+        assert s.stride % 8 == 0 and s.c_base % 8 == 0 and s.channels % 8 == 0, "f16x3 sources need C % 8 == 0"
+        n_slots = 0
+        for r in range(kh):
+            for q in range(kw):
+                for g in range(s.channels // 8):
+                    slots.append([si, r * dilation - pad, q * dilation - pad, s.c_base + 8 * g])
+                    cols.append((c_lo + 8 * g, r, q))
+                    n_slots += 1
+        while n_slots % 4:
+            slots.append([si, 0, 0, -1])
+            cols.append((-1, 0, 0))
+            n_slots += 1
+        c_lo += s.channels
+    k_pad = len(slots) * 8
+    w = torch.zeros(n_pad, k_pad, dtype=torch.float64)
+    wf = weight.double()
+    for j, (c0, r, q) in enumerate(cols):
+        if c0 >= 0:
+            w[:co, 8 * j:8 * j + 8] = wf[:, c0:c0 + 8, r, q]
+    wmax = float(w.abs().max())
+    s_exp = int(torch.floor(torch.log2(torch.tensor(16384.0 / wmax)))) if wmax > 0 else 0
+    ws = (w * 2.0 ** s_exp).float()
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    planes = torch.stack([hi, lo], 0)
+    f = planes.view(2, n_pad // 32, 32, k_pad // 16, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+    b = torch.zeros(n_pad)
+    b[:co] = bias
+    pc = PackedConv(f.view(n_pad // 32, k_pad // 16, 2, 64, 8), b, torch.tensor(slots, dtype=torch.int32),
+                    co, n_pad, k_pad, kh, stride, pad, tuple(s.channels for s in sources))
+    pc.out_scale = 2.0 ** -(s_exp + 4)
+    return pc
 
 
 def pack_fragments(weight2d, n_pad=None):

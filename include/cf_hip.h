@@ -77,6 +77,7 @@ typedef struct cf_conv_args {
   int32_t out_layout;           /* CF_LAYOUT_*                                                        */
   int32_t act;                  /* CF_ACT_*                                                           */
   int32_t precise;              /* !=0: two-level (per-32-K-chunk) fp32 summation, see cf_gemm.hip    */
+  float out_scale;              /* cf_conv2d_f16x3 only: 2^-(s+4), s = weight scale exponent          */
 } cf_conv_args;
 int cf_conv2d_fused(const cf_conv_args* a, void* stream);
 
@@ -89,6 +90,14 @@ int cf_conv2d_fused(const cf_conv_args* a, void* stream);
  * [N_pad][2][K_pad] bf16 (hi plane, lo plane); out is either CF_LAYOUT_NHWC_SPLIT_BF16
  * (out_stride = channels per plane) or CF_LAYOUT_NCHW fp32; residual / precise are ignored. */
 int cf_conv2d_bf16x3(const cf_conv_args* a, void* stream);
+
+/* cf_conv2d_f16x3: cf_conv2d_fused semantics (fp32 NHWC sources / residual / output, bias, ReLU) with
+ * the products evaluated on the f16 MFMA pipe from split operands (x = hi + lo fp16 after a
+ * power-of-two scale): fp32-level accuracy at ~3x the fp32-MFMA rate (cf_gemm_f16.hip).  Differences
+ * in the argument block: one slot = 8 channels (src_c multiples of 8, K_pad = 8 * n_slots, multiple
+ * of 32); weight = fragment-packed fp16 hi/lo planes of 2^s * W (packing.pack_conv_f16);
+ * out_scale = 2^-(s+4); N_pad is 32 or a multiple of 64; output layout NHWC only; act NONE / RELU. */
+int cf_conv2d_f16x3(const cf_conv_args* a, void* stream);
 
 /* cf_split_bf16: fp32 NHWC [M][in_stride] (C used) -> split-bf16 [M][2][Cs], channels C..Cs-1 zero. */
 int cf_split_bf16(const float* x, void* out, long M, int C, int in_stride, int Cs, void* stream);

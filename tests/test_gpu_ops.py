@@ -468,3 +468,49 @@ def test_post_process_vs_reference_golden(dev, golden_dir, seed):
     if seed == 1:
         bad = (g["dimension"] <= 0).any(-1)
         assert bad.any() and not pp["bboxes3d"].cpu().numpy()[bad].any()
+
+
+# ----------------------------------------------------------------------- f16x3 (fp32 storage)
+@pytest.mark.parametrize("B,Ci,Co,H,W,k,stride,act,res", [
+    (2, 16, 32, 40, 56, 3, 2, 1, False),     # level1: N_pad 32 (RT=1)
+    (1, 64, 64, 28, 50, 3, 1, 1, True),      # level2 block conv2 + residual, (1,4) waves
+    (2, 64, 128, 30, 26, 3, 2, 1, False),    # (2,2) waves, stride 2, ragged M
+    (2, 128, 256, 14, 25, 3, 1, 1, True),    # (4,1) waves
+    (1, 256, 512, 14, 25, 3, 2, 1, False),   # two channel blocks
+    (3, 64, 27, 23, 31, 3, 1, 0, False),     # conv_offset_mask (N=27), ragged M
+])
+def test_conv2d_f16x3_fp32_level_accuracy(dev, B, Ci, Co, H, W, k, stride, act, res):
+    from centerfusiondetect3d_amd import ops, packing
+    x, w, b = F.relu(rnd(B, Ci, H, W, seed=1)) * 3, rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5), rnd(Co, seed=3)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride, k // 2)
+    r = rnd(*ref.shape, seed=6) if res else None
+    if res:
+        ref = ref + r.double()
+    if act:
+        ref = F.relu(ref)
+    pc = packing.pack_conv_f16(w, b, [packing.Source(Ci, Ci)], stride=stride).to(dev)
+    stride_out = 32 if Co == 27 else Co
+    out = torch.zeros(B, ref.shape[2], ref.shape[3], stride_out, device=dev)
+    ops.conv2d_f16x3(pc, [nhwc(x).to(dev)], B, H, W, act=act, residual=nhwc(r).to(dev) if res else None, out=out)
+    got = nchw(out[..., :Co]).cpu().double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    ref32 = F.conv2d(x, w, b, stride, k // 2)
+    if res:
+        ref32 = ref32 + r
+    if act:
+        ref32 = F.relu(ref32)
+    err32 = float((ref32.double() - ref).abs().max() / ref.abs().max())
+    print(f"[f16x3] K={Ci * k * k}: max|err|/max|ref| = {err:.2e} (torch fp32 conv: {err32:.2e})")
+    assert err < 1.5e-6, err
+
+
+def test_conv2d_f16x3_root_concat(dev):
+    from centerfusiondetect3d_amd import ops, packing
+    B, H, W = 2, 14, 25
+    chans = [128, 128, 64, 128]
+    xs = [rnd(B, c, H, W, seed=10 + i) for i, c in enumerate(chans)]
+    w = rnd(128, sum(chans), 1, 1, seed=20, scale=sum(chans) ** -0.5)
+    ref = F.relu(F.conv2d(torch.cat(xs, 1).double(), w.double()))
+    pc = packing.pack_conv_f16(w, torch.zeros(128), [packing.Source(c, c) for c in chans]).to(dev)
+    out = ops.conv2d_f16x3(pc, [nhwc(x).to(dev) for x in xs], B, H, W, act=1)
+    assert float((nchw(out).cpu().double() - ref).abs().max() / ref.abs().max()) < 1.5e-6

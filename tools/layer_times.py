@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--fp32-heads", action="store_true")
 ap.add_argument("--no-precise", action="store_true")
+ap.add_argument("--fp32-convs", action="store_true")
 ap.add_argument("--iters", type=int, default=5)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -17,6 +18,7 @@ H, W = 448, 800
 m = getModel(centerfusion_middle_config((H, W)))
 m.heads_bf16 = not a.fp32_heads
 m.precise = not a.no_precise
+m.conv_f16 = not a.fp32_convs
 m = bench.synthetic_weights(m).to(dev).eval()
 images, pc_dep, calib = bench.make_inputs(a.batch, H, W, dev, 1000)
 with torch.no_grad():

@@ -26,12 +26,15 @@ def stages(sd_, x_):
     return d
 with torch.no_grad():
     r32 = stages(sd, x); r64 = stages(sd64, x.double())
-m = getModel(centerfusion_middle_config((H,W))); m.load_state_dict(sd); m=m.cuda()
+import os as _os
+m = getModel(centerfusion_middle_config((H,W))); m.load_state_dict(sd)
+m.conv_f16 = _os.environ.get('CF_F16','1')=='1'; m=m.cuda()
 with torch.no_grad():
     out = m(x.cuda(), pc_dep=pc_dep.cuda(), calib=calib.cuda())
 plan = list(m._plans.values())[0]
 dbg = dict(plan.debug); dbg["feat"]=plan.feat
 def nerr(a,b): return float((a-b).abs().max()/b.abs().max())
+def rerr(a,b): return float((a-b).pow(2).mean().sqrt()/b.pow(2).mean().sqrt())
 for k in r64:
     g = dbg[k].permute(0,3,1,2).double().cpu()
-    print(f"{k:>5s}: gpu-vs-fp64 {nerr(g,r64[k]):.2e}   cpu32-vs-fp64 {nerr(r32[k].double(),r64[k]):.2e}   gpu-vs-cpu32 {nerr(g,r32[k].double()):.2e}")
+    print(f"{k:>5s}: max-norm gpu-vs-fp64 {nerr(g,r64[k]):.2e} cpu32-vs-fp64 {nerr(r32[k].double(),r64[k]):.2e} | rms gpu-vs-fp64 {rerr(g,r64[k]):.2e} cpu32-vs-fp64 {rerr(r32[k].double(),r64[k]):.2e}")
