@@ -231,8 +231,213 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvF p) {
   }
 }
 
-template <typename K>
-void launch_f16(K kernel, dim3 grid, size_t dyn, hipStream_t st, const ConvF& args) {
+// ---------------------------------------------------------------------------------------------
+// DCNv2 main GEMM on the same f16x3 scheme.  The B operand is the bilinear sample: per (pixel, tap)
+// the sampling position and 16*sigmoid(mask) are computed once per tile into LDS; per chunk a thread
+// requests the 4 corner rows (8 fp32 channels each) of its (pixel, unit) pairs one chunk ahead,
+// combines them in fp32, splits to fp16 hi/lo and stages them.  The VALU work per sample (~14
+// instructions) is what bounds the 64-output-channel layers, not the MFMA pipe.
+// ---------------------------------------------------------------------------------------------
+struct DcnF {
+  const float* x;
+  const float* om;
+  const unsigned char* weight;
+  const float* bias;
+  float* out;
+  int om_stride, H, W, C, n_chunks, chunks_per_tap, out_stride, act, M, N, n_rt;
+  float out_scale;
+};
+
+template <int WC, int WP, int RT>
+__global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
+  static_assert(WC * WP == 4, "4 waves per workgroup");
+  constexpr int PXB = 64 * WP;
+  constexpr int PLANE = PXB * FROWB;
+  constexpr int BUF = 2 * PLANE;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + PXB * 9 * 16];
+  f32x4* desc = reinterpret_cast<f32x4*>(smem + 2 * BUF);   // {h, w, 16*sigmoid(mask), -} per (pixel, tap)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wc = wave / WP, wp = wave % WP;
+  const int m0 = blockIdx.x * PXB;
+  const int rt0 = (blockIdx.y * WC + wc) * RT;
+  const bool w_ok = rt0 < p.n_rt;
+  const int n_ks = p.n_chunks * 2;
+  const int HW = p.H * p.W;
+
+  for (int i = tid; i < PXB * 9; i += 256) {
+    const int r = i / 9, tap = i - r * 9;
+    const int m = m0 + r;
+    f32x4 d = {-1.0e9f, -1.0e9f, 0.0f, 0.0f};
+    if (m < p.M) {
+      const int b = m / HW, rem = m - b * HW;
+      const int ho = rem / p.W, wo = rem - ho * p.W;
+      const float* om = p.om + (size_t)m * p.om_stride;
+      const int ti = tap / 3, tj = tap - ti * 3;
+      d[0] = (float)(ho - 1 + ti) + om[2 * tap];
+      d[1] = (float)(wo - 1 + tj) + om[2 * tap + 1];
+      d[2] = cf_sigmoid(om[18 + tap]) * ASCALE;
+    }
+    desc[i] = d;
+  }
+  int boff[WP];
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    const int m = m0 + ((tid + 256 * i) >> 2);
+    boff[i] = (m < p.M ? m / HW : 0) * HW;
+  }
+  __syncthreads();
+
+  f32x4 cv[WP][4][2];   // 4 corners x 8 channels, requested one chunk ahead
+  f32x4 cw[WP];         // corner weights (mask and activation scale folded in)
+  auto load_b = [&](int c) {
+    const int tap = c / p.chunks_per_tap;
+    const int c0 = (c - tap * p.chunks_per_tap) * 32 + (tid & 3) * 8;
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const f32x4 d = desc[((tid + 256 * i) >> 2) * 9 + tap];
+      const float hf = d[0], wf = d[1];
+      const bool inside = hf > -1.0f && hf < (float)p.H && wf > -1.0f && wf < (float)p.W;
+      const float hfl = floorf(hf), wfl = floorf(wf);
+      const int hl = (int)hfl, wl = (int)wfl;
+      const float lh = hf - hfl, lw = wf - wfl, hh = 1.0f - lh, hw = 1.0f - lw;
+      const bool t_ok = inside && hl >= 0, b_ok = inside && hl + 1 <= p.H - 1;
+      const bool l_ok = wl >= 0, r_ok = wl + 1 <= p.W - 1;
+      const float* base = p.x + (size_t)boff[i] * p.C + c0;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const float* a0 = base + (size_t)(hl * p.W + wl) * p.C;
+      const float* a1 = a0 + p.C;
+      const float* a2 = a0 + (size_t)p.W * p.C;
+      const float* a3 = a2 + p.C;
+      cv[i][0][0] = (t_ok && l_ok) ? *reinterpret_cast<const f32x4*>(a0) : z;
+      cv[i][0][1] = (t_ok && l_ok) ? *reinterpret_cast<const f32x4*>(a0 + 4) : z;
+      cv[i][1][0] = (t_ok && r_ok) ? *reinterpret_cast<const f32x4*>(a1) : z;
+      cv[i][1][1] = (t_ok && r_ok) ? *reinterpret_cast<const f32x4*>(a1 + 4) : z;
+      cv[i][2][0] = (b_ok && l_ok) ? *reinterpret_cast<const f32x4*>(a2) : z;
+      cv[i][2][1] = (b_ok && l_ok) ? *reinterpret_cast<const f32x4*>(a2 + 4) : z;
+      cv[i][3][0] = (b_ok && r_ok) ? *reinterpret_cast<const f32x4*>(a3) : z;
+      cv[i][3][1] = (b_ok && r_ok) ? *reinterpret_cast<const f32x4*>(a3 + 4) : z;
+      const f32x4 w = {hh * hw, hh * lw, lh * hw, lh * lw};
+      cw[i] = w;   // the mask (x 2^4 activation scale) is applied after the 4-corner sum, as the reference does
+    }
+  };
+  auto store_b = [&](unsigned char* buf, int c) {
+    const int tap = c / p.chunks_per_tap;
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      const int pr = tid + 256 * i;
+      const float mk = desc[(pr >> 2) * 9 + tap][2];
+      f32x4 v0 = (cw[i][0] * cv[i][0][0] + cw[i][1] * cv[i][1][0] + cw[i][2] * cv[i][2][0] + cw[i][3] * cv[i][3][0]) * mk;
+      f32x4 v1 = (cw[i][0] * cv[i][0][1] + cw[i][1] * cv[i][1][1] + cw[i][2] * cv[i][2][1] + cw[i][3] * cv[i][3][1]) * mk;
+      _Float16 hv[8], lv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xx = __builtin_amdgcn_fmed3f(e < 4 ? v0[e] : v1[e - 4], -65504.0f, 65504.0f);
+        hv[e] = (_Float16)xx;
+        lv[e] = (_Float16)(xx - (float)hv[e]);
+      }
+      u32x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = pack_h2(hv[2 * e], hv[2 * e + 1]);
+        lo[e] = pack_h2(lv[2 * e], lv[2 * e + 1]);
+      }
+      unsigned char* o = buf + (pr >> 2) * FROWB + (pr & 3) * 16;
+      *reinterpret_cast<u32x4*>(o) = hi;
+      *reinterpret_cast<u32x4*>(o + PLANE) = lo;
+    }
+  };
+
+  f32x16 accm[RT][2], accs[RT][2];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        accm[a][b][r] = 0.0f;
+        accs[a][b][r] = 0.0f;
+      }
+  f16x8 wh[2][RT], wl[2][RT];
+  auto load_w = [&](f16x8 (&dh)[RT], f16x8 (&dl)[RT], int ks) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      dh[rt] = *wfrag16(p.weight, w_ok ? rt0 + rt : 0, ks, 0, n_ks, lane);
+      dl[rt] = *wfrag16(p.weight, w_ok ? rt0 + rt : 0, ks, 1, n_ks, lane);
+    }
+  };
+  auto mma_kstep = [&](const unsigned char* buf, int s, const f16x8 (&ah)[RT], const f16x8 (&al)[RT]) {
+    f16x8 xh[2], xl[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const unsigned char* row = buf + (wp * 64 + ct * 32 + li) * FROWB + s * 32 + h * 16;
+      xh[ct] = *reinterpret_cast<const f16x8*>(row);
+      xl[ct] = *reinterpret_cast<const f16x8*>(row + PLANE);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rt], xh[ct], accs[rt][ct], 0, 0, 0);
+        accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rt], xl[ct], accs[rt][ct], 0, 0, 0);
+        accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rt], xh[ct], accm[rt][ct], 0, 0, 0);
+      }
+  };
+
+  load_b(0);
+  load_w(wh[0], wl[0], 0);
+  load_w(wh[1], wl[1], 1);
+  store_b(smem, 0);
+  if (p.n_chunks > 1) load_b(1);
+  __syncthreads();
+  for (int c = 0; c < p.n_chunks; ++c) {
+    unsigned char* cur = smem + (c & 1) * BUF;
+    unsigned char* nxt = smem + ((c + 1) & 1) * BUF;
+    mma_kstep(cur, 0, wh[0], wl[0]);
+    if (c + 1 < p.n_chunks) load_w(wh[0], wl[0], 2 * c + 2);
+    mma_kstep(cur, 1, wh[1], wl[1]);
+    if (c + 1 < p.n_chunks) {
+      load_w(wh[1], wl[1], 2 * c + 3);
+      store_b(nxt, c + 1);
+      if (c + 2 < p.n_chunks) load_b(c + 2);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int m = m0 + wp * 64 + ct * 32 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = (rt0 + rt) * 32 + 8 * g + 4 * h;
+        if (n >= p.N) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
+        if (n + 3 < p.N) {
+          v += *reinterpret_cast<const f32x4*>(p.bias + n);
+          if (p.act == CF_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+          }
+          *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.out_stride + n) = v;
+        } else {
+          for (int e = 0; e < 4 && n + e < p.N; ++e) {
+            float x = v[e] + p.bias[n + e];
+            if (p.act == CF_ACT_RELU) x = fmaxf(x, 0.0f);
+            p.out[(size_t)m * p.out_stride + n + e] = x;
+          }
+        }
+      }
+  }
+}
+
+template <typename K, typename A>
+void launch_f16(K kernel, dim3 grid, size_t dyn, hipStream_t st, const A& args) {
   static size_t limit = 0;
   if (dyn > limit) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -289,4 +494,35 @@ extern "C" int cf_conv2d_f16x3(const cf_conv_args* a, void* stream) {
     launch_f16(conv_f16x3_kernel<4, 1, 2, true>, dim3((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 255) / 256)), dyn, st, k);
   }
   return cf_check_launch("cf_conv2d_f16x3");
+}
+
+extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
+  CF_REQUIRE(a != nullptr, "cf_dcn_v2_f16x3: null args");
+  CF_REQUIRE(a->C > 0 && a->C % 32 == 0, "cf_dcn_v2_f16x3: C=%d not a multiple of 32", a->C);
+  CF_REQUIRE(a->N > 0 && a->N_pad >= a->N && a->N_pad % 32 == 0, "cf_dcn_v2_f16x3: N=%d N_pad=%d", a->N, a->N_pad);
+  CF_REQUIRE(a->om_stride >= 27, "cf_dcn_v2_f16x3: om_stride=%d < 27", a->om_stride);
+  CF_REQUIRE(a->x && a->offmask && a->weight && a->bias && a->out, "cf_dcn_v2_f16x3: null buffer");
+  CF_REQUIRE(a->out_stride >= a->N && a->out_stride % 4 == 0, "cf_dcn_v2_f16x3: bad out_stride");
+  CF_REQUIRE(a->act == CF_ACT_NONE || a->act == CF_ACT_RELU, "cf_dcn_v2_f16x3: act=%d unsupported", a->act);
+  CF_REQUIRE(a->out_scale > 0.0f, "cf_dcn_v2_f16x3: out_scale missing");
+  const long M = (long)a->B * a->H * a->W;
+  CF_REQUIRE(M > 0 && M < (1L << 31), "cf_dcn_v2_f16x3: bad geometry");
+  DcnF k{};
+  k.x = a->x; k.om = a->offmask; k.weight = reinterpret_cast<const unsigned char*>(a->weight);
+  k.bias = a->bias; k.out = a->out;
+  k.om_stride = a->om_stride; k.H = a->H; k.W = a->W; k.C = a->C;
+  k.n_chunks = 9 * a->C / 32;
+  k.chunks_per_tap = a->C / 32;
+  k.out_stride = a->out_stride; k.act = a->act; k.M = (int)M; k.N = a->N;
+  k.n_rt = a->N_pad / 32;
+  k.out_scale = a->out_scale;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->N_pad <= 64) {          // 64 channels: 2 x 32-channel wave rows, 2 x 64 pixels
+    launch_f16(dcn_f16x3_kernel<2, 2, 1>, dim3((unsigned)((M + 127) / 128), (unsigned)((a->N_pad + 63) / 64)), 0, st, k);
+  } else if (a->N_pad <= 128) {  // 128 channels: 4 x 32-channel wave rows, 64 pixels
+    launch_f16(dcn_f16x3_kernel<4, 1, 1>, dim3((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 127) / 128)), 0, st, k);
+  } else {
+    launch_f16(dcn_f16x3_kernel<4, 1, 2>, dim3((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 255) / 256)), 0, st, k);
+  }
+  return cf_check_launch("cf_dcn_v2_f16x3");
 }

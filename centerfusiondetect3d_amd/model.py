@@ -239,7 +239,7 @@ class _Plan:
             self.keep.append(a)
             self.step_index[p] = len(self.steps)
             self.step_flops[p] = 2.0 * B * h * w * pd.n * 9 * pd.c
-            self.steps.append((self.lib.cf_dcn_v2_fused, C.byref(a)))
+            self.steps.append((self.lib.cf_dcn_v2_f16x3 if pd.out_scale > 0 else self.lib.cf_dcn_v2_fused, C.byref(a)))
             return o
 
         def ida(p, layers, startp, endp):
@@ -546,7 +546,7 @@ class DLASeg(nn.Module):
 
         def dcn(p, ci, co):
             w, b = packing.fold_bn(sd[p + ".weight"], sd[p + ".bias"], bn(p + ".activation.0"))
-            pk[p] = packing.pack_dcn(w, b).to(device)
+            pk[p] = (packing.pack_dcn_f16 if f16 else packing.pack_dcn)(w, b).to(device)
             pk[p + ".conv_offset_mask"] = pack_any(
                 sd[p + ".conv_offset_mask.weight"].float().cpu(),
                 sd[p + ".conv_offset_mask.bias"].float().cpu(), [Source(ci, ci)])

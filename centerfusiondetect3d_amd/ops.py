@@ -170,11 +170,13 @@ def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act
     a.weight, a.bias, a.N, a.N_pad = pd.weight.data_ptr(), pd.bias.data_ptr(), pd.n, pd.n_pad
     a.out, a.out_stride, a.act = out.data_ptr(), out_stride, act
     a.precise = int(bool(precise))
+    a.out_scale = float(getattr(pd, "out_scale", 0.0))
     return a
 
 
 def run_dcn(a: _lib.DcnArgs):
-    _lib.check(_lib.load().cf_dcn_v2_fused(C.byref(a), _lib.stream_ptr()), "cf_dcn_v2_fused")
+    fn = _lib.load().cf_dcn_v2_f16x3 if a.out_scale > 0 else _lib.load().cf_dcn_v2_fused
+    _lib.check(fn(C.byref(a), _lib.stream_ptr()), "cf_dcn_v2")
 
 
 def dcn_v2_fused(pd: PackedDcn, x, offmask, act=ACT_RELU, precise=True):

@@ -209,6 +209,7 @@ class PackedDcn:
     n: int
     n_pad: int
     c: int
+    out_scale: float = 0.0   # cf_dcn_v2_f16x3: 2^-(s+4)
 
     def to(self, device):
         self.weight = self.weight.to(device).contiguous()
@@ -225,6 +226,26 @@ def pack_dcn(weight, bias) -> PackedDcn:
     b = torch.zeros(n_pad)
     b[:co] = bias
     return PackedDcn(w, b, co, n_pad, ci)
+
+
+def pack_dcn_f16(weight, bias) -> PackedDcn:
+    """cf_dcn_v2_f16x3: K order (tap, channel), weights 2^s-scaled, fp16 hi/lo, fragment order."""
+    co, ci, kh, kw = weight.shape
+    assert (kh, kw) == (3, 3) and ci % BK == 0
+    n_pad = ((co + 31) // 32) * 32
+    w = torch.zeros(n_pad, 9 * ci, dtype=torch.float64)
+    w[:co] = weight.double().permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    wmax = float(w.abs().max())
+    s_exp = int(torch.floor(torch.log2(torch.tensor(16384.0 / wmax)))) if wmax > 0 else 0
+    ws = (w * 2.0 ** s_exp).float()
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    f = torch.stack([hi, lo], 0).view(2, n_pad // 32, 32, 9 * ci // 16, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+    b = torch.zeros(n_pad)
+    b[:co] = bias
+    pd = PackedDcn(f.view(n_pad // 32, 9 * ci // 16, 2, 64, 8), b, co, n_pad, ci)
+    pd.out_scale = 2.0 ** -(s_exp + 4)
+    return pd
 
 
 def pack_upsample(weight):

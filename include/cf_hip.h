@@ -166,8 +166,14 @@ typedef struct cf_dcn_args {
   int32_t out_stride;
   int32_t act;
   int32_t precise;      /* as cf_conv_args.precise              */
+  float out_scale;      /* cf_dcn_v2_f16x3 only: 2^-(s+4)       */
 } cf_dcn_args;
 int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream);
+
+/* cf_dcn_v2_f16x3: cf_dcn_v2_fused with the main GEMM on the f16 MFMA pipe from split operands (see
+ * cf_conv2d_f16x3); weight = fragment-packed fp16 hi/lo planes of 2^s * W in (tap, channel) K order
+ * (packing.pack_dcn_f16), out_scale = 2^-(s+4).  x / offmask / out stay fp32 NHWC. */
+int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream);
 
 /* cf_upsample_dw: depthwise transposed conv (k = 2f, stride f, pad f/2, groups = C, no bias),
  * optionally fused with the IDA skip add:  out = convT(x) [+ skip].

@@ -514,3 +514,24 @@ def test_conv2d_f16x3_root_concat(dev):
     pc = packing.pack_conv_f16(w, torch.zeros(128), [packing.Source(c, c) for c in chans]).to(dev)
     out = ops.conv2d_f16x3(pc, [nhwc(x).to(dev) for x in xs], B, H, W, act=1)
     assert float((nchw(out).cpu().double() - ref).abs().max() / ref.abs().max()) < 1.5e-6
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,mag", [(2, 64, 64, 28, 50, 2.0), (1, 128, 64, 14, 25, 8.0),
+                                             (1, 512, 256, 7, 13, 1.0), (2, 256, 128, 9, 11, 30.0),
+                                             (1, 128, 128, 20, 23, 3.0)])
+def test_dcn_v2_f16x3(dev, B, Ci, Co, H, W, mag):
+    from centerfusiondetect3d_amd import ops, packing
+    x = rnd(B, Ci, H, W, seed=1)
+    om = rnd(B, 27, H, W, seed=2)
+    om[:, :18] *= mag
+    w, b = rnd(Co, Ci, 3, 3, seed=3, scale=(Ci * 9) ** -0.5), rnd(Co, seed=4)
+    o1, o2, m = torch.chunk(om, 3, dim=1)
+    ref = F.relu(dcn_ref.deform_conv2d(x.double(), torch.cat((o1, o2), 1).double(), w.double(), b.double(),
+                                       (1, 1), (1, 1), (1, 1), torch.sigmoid(m.double())))
+    pd = packing.pack_dcn_f16(w, b).to(dev)
+    om32 = torch.zeros(B, H, W, 32)
+    om32[..., :27] = nhwc(om)
+    out = ops.dcn_v2_fused(pd, nhwc(x).to(dev), om32.to(dev))
+    err = float((nchw(out).cpu().double() - ref).abs().max() / ref.abs().max())
+    print(f"[dcn f16x3] C={Ci}->{Co}: max|err|/max|ref| = {err:.2e}")
+    assert err < 5e-6, err
