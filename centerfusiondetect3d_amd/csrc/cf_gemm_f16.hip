@@ -180,20 +180,32 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvF p) {
   load_w(wh[0], wl[0], 0);
   load_w(wh[1], wl[1], 1);
   store_b(smem);
-  if (p.n_chunks > 1) load_b(1);
+  load_b(p.n_chunks > 1 ? 1 : 0);
   __syncthreads();
+  // Straight-line body (indices clamped instead of branches) so the scheduler may interleave the
+  // VALU operand split of chunk c+1 with the MFMAs of chunk c (sched_group_barrier pattern below).
+  const int last = p.n_chunks - 1;
   for (int c = 0; c < p.n_chunks; ++c) {
     unsigned char* cur = smem + (DB ? (c & 1) * BUF : 0);
     unsigned char* nxt = smem + (DB ? ((c + 1) & 1) * BUF : 0);
     mma_kstep(cur, 0, wh[0], wl[0]);
-    if (c + 1 < p.n_chunks) load_w(wh[0], wl[0], 2 * c + 2);
-    mma_kstep(cur, 1, wh[1], wl[1]);
-    if (!DB) __syncthreads();               // single buffer: everyone is done reading it
-    if (c + 1 < p.n_chunks) {
-      load_w(wh[1], wl[1], 2 * c + 3);
-      store_b(nxt);                         // chunk c+1 (requested one chunk ago)
-      if (c + 2 < p.n_chunks) load_b(c + 2);
+    load_w(wh[0], wl[0], min(2 * c + 2, n_ks - 2));
+    if (!DB) {
+      mma_kstep(cur, 1, wh[1], wl[1]);
+      load_w(wh[1], wl[1], min(2 * c + 3, n_ks - 1));
+      __syncthreads();                      // single buffer: everyone is done reading it
+      store_b(nxt);
+    } else {
+      store_b(nxt);                         // chunk c+1 (requested one chunk ago): VALU split + 2 LDS writes
+      mma_kstep(cur, 1, wh[1], wl[1]);
+      load_w(wh[1], wl[1], min(2 * c + 3, n_ks - 1));
+#pragma unroll
+      for (int i = 0; i < 6 * RT; ++i) {    // pair every MFMA of the chunk with a few VALU / DS ops
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 4 * WP, 0);   // VALU
+      }
     }
+    load_b(min(c + 2, last));
     __syncthreads();
   }
 
