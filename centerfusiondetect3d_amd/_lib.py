@@ -46,7 +46,7 @@ class HeadTailArgs(C.Structure):
 class HeadFusedArgs(C.Structure):
     _fields_ = [("tail", HeadTailArgs), ("src", _f * 2), ("src_c", C.c_int32 * 2), ("n_src", C.c_int32),
                 ("slots", _f), ("K_pad", C.c_int32), ("w_first", _f * CF_MAX_HEADS),
-                ("b_first", _f * CF_MAX_HEADS)]
+                ("b_first", _f * CF_MAX_HEADS), ("layout3x3", C.c_int32), ("w_out_perm", _f * CF_MAX_HEADS)]
 
 
 class DecodeArgs(C.Structure):
@@ -62,6 +62,7 @@ SYMBOLS = {
     "cf_conv2d_fused": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_conv2d_bf16x3": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_conv2d_f16x3": (_i, [C.POINTER(ConvArgs), _f]),
+    "cf_conv3x3_f16x3": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_split_bf16": (_i, [_f, _f, C.c_long, _i, _i, _i, _f]),
     "cf_head_tail": (_i, [C.POINTER(HeadTailArgs), _f]),
     "cf_head_fused": (_i, [C.POINTER(HeadFusedArgs), _f]),

@@ -1,0 +1,336 @@
+// 3x3 / stride 1 / pad 1 convolution on the f16x3 scheme (fp32 storage, split-fp16 products - see the
+// numerics note in cf_gemm_f16.hip) with PATCH REUSE: the generic slot kernel re-gathers and re-splits
+// every input element once per tap (9x); here a workgroup owns R = 64*WP consecutive pixels of the
+// flattened (B*H*W) index space and, per 16-channel slice, stages the flat row range
+//     [m0 - W - 1, m0 + R + W + 1)
+// ONCE - fp32 rows -> fp16 hi/lo -> LDS.  All 9 taps then read their B fragments from that patch at
+// row offset (dy+1)*W + (dx+1); a lane whose tap leaves the image (or the batch element) is pointed
+// at an all-zero row instead, so borders cost one select per fragment address.  Per slice that is one
+// barrier and one operand split for 9 k-steps of MFMA work, and (R + 2W + 2)/R <= 2.6x input
+// traffic instead of 9x.
+//
+// K order is SLICE-MAJOR: k-step index ks = slice * 9 + tap (packing.pack_conv_f16(slice_major=True)
+// emits the slot table in that order, so the generic kernel cf_conv2d_f16x3 computes the same sums
+// from the same packed weights - it is the fallback for feature maps too wide for the LDS patch).
+//
+// Workgroup = 4 waves as WC (32*RT-channel groups) x WP (64-pixel groups) x WK (slices in flight:
+// the patch then carries 16*WK channels per round and wave wk multiplies slice wk; partial sums are
+// added in fixed wave order through LDS at the end).  WK > 1 is for small feature maps with many
+// input channels (the 14x25 / 28x50 offset convolutions), where pixel tiles alone cannot fill 256 CUs.
+//
+// Replaces the 3x3 stride-1 convolutions of model/networks/dla.py:42-62 (BasicBlock conv1/conv2) and
+// the conv_offset_mask of model/networks/dla.py:406-414 (DeformConv) on the device.
+#include "cf_f16x3.h"
+
+namespace {
+
+struct Conv3F {
+  const float* x;               // fp32 NHWC, first channel of the source
+  const unsigned char* weight;  // [N_pad/32][n_ks][2][64][8 f16]
+  const float* bias;
+  const float* residual;
+  float* out;
+  int x_stride, H, W, HW, M, N, n_rt, n_ks, n_rounds, res_stride, out_stride, act, PR;
+  float out_scale;
+};
+
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
+  static_assert(WC * WP * WK == 4, "4 waves per workgroup");
+  constexpr int R = 64 * WP;
+  constexpr int ROWB = 64 * WK + 16;        // per patch row: WK x (16 hi + 16 lo f16) + pad (odd multiple of 16 B)
+  constexpr int UPR = 4 * WK;               // 16-byte fp32 units per patch row
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wk = wave % WK, wp = (wave / WK) % WP, wc = wave / (WK * WP);
+  const int m0 = blockIdx.x * R;
+  const int rt0 = (blockIdx.y * WC + wc) * RT;
+  const bool w_ok = rt0 < p.n_rt;
+  const int bufb = (p.PR + 1) * ROWB;       // + the zero row
+  const int zrow = p.PR * ROWB + wk * 64 + h * 16;
+
+  // zero rows of both buffers
+  if (tid < ROWB / 4) {
+    *reinterpret_cast<unsigned*>(smem + p.PR * ROWB + tid * 4) = 0u;
+    if (DB) *reinterpret_cast<unsigned*>(smem + bufb + p.PR * ROWB + tid * 4) = 0u;
+  }
+
+  // ---- staging role: NU (patch row, 4-channel unit) pairs per thread
+  int goff[NU];                              // element offset of the unit in x for round 0, -1 = zeros
+#pragma unroll
+  for (int it = 0; it < NU; ++it) {
+    const int u = tid + 256 * it;
+    const int row = u / UPR, q = u % UPR;
+    const int g = m0 - p.W - 1 + row;
+    goff[it] = (row < p.PR && g >= 0 && g < p.M) ? g * p.x_stride + 4 * q : -1;
+  }
+  f32x4 raw[NU];
+  auto load_patch = [&](int r) {
+    const int c0 = r * 16 * WK;
+#pragma unroll
+    for (int it = 0; it < NU; ++it) {
+      raw[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (goff[it] >= 0) raw[it] = *reinterpret_cast<const f32x4*>(p.x + goff[it] + c0);
+    }
+  };
+  auto store_patch = [&](unsigned char* buf) {
+#pragma unroll
+    for (int it = 0; it < NU; ++it) {
+      const int u = tid + 256 * it;
+      const int row = u / UPR, q = u % UPR;
+      if (row < p.PR) {
+        _Float16 hv[4], lv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xx = __builtin_amdgcn_fmed3f(raw[it][e] * ASCALE, -65504.0f, 65504.0f);
+          hv[e] = (_Float16)xx;
+          lv[e] = (_Float16)(xx - (float)hv[e]);
+        }
+        unsigned char* o = buf + row * ROWB + (q >> 2) * 64 + (q & 3) * 8;
+        *reinterpret_cast<uint2*>(o) = uint2{pack_h2(hv[0], hv[1]), pack_h2(hv[2], hv[3])};
+        *reinterpret_cast<uint2*>(o + 32) = uint2{pack_h2(lv[0], lv[1]), pack_h2(lv[2], lv[3])};
+      }
+    }
+  };
+
+  // ---- MFMA role: per column tile the patch row of this lane's pixel and its 9-bit tap validity
+  int rowb[2];
+  unsigned vmask[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int pl = wp * 64 + ct * 32 + li;
+    const int m = m0 + pl;
+    rowb[ct] = pl * ROWB + wk * 64 + h * 16;
+    unsigned mk = 0;
+    if (m < p.M) {
+      const int rem = m % p.HW;
+      const int y = rem / p.W, x = rem - y * p.W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) mk |= 1u << t;
+      }
+    }
+    vmask[ct] = mk;
+  }
+
+  f32x16 accm[RT][2], accs[RT][2];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        accm[a][b][r] = 0.0f;
+        accs[a][b][r] = 0.0f;
+      }
+
+  // weight fragments three taps ahead: set (t % 3) holds tap t
+  f16x8 wh[3][RT], wl[3][RT];
+  const int ks_last = (p.n_rounds * WK - WK + wk) * 9 + 8;      // this wave's last k-step
+  auto load_w = [&](f16x8 (&dh)[RT], f16x8 (&dl)[RT], int ks) {
+    ks = min(ks, ks_last);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      dh[rt] = *wfrag16(p.weight, w_ok ? rt0 + rt : 0, ks, 0, p.n_ks, lane);
+      dl[rt] = *wfrag16(p.weight, w_ok ? rt0 + rt : 0, ks, 1, p.n_ks, lane);
+    }
+  };
+
+  load_patch(0);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) load_w(wh[t], wl[t], wk * 9 + t);
+  store_patch(smem);
+  __syncthreads();
+
+  for (int r = 0; r < p.n_rounds; ++r) {
+    const unsigned char* cur = smem + (DB ? (r & 1) * bufb : 0);
+    unsigned char* nxt = smem + (DB ? ((r + 1) & 1) * bufb : 0);
+    const bool more = r + 1 < p.n_rounds;
+    if (more) load_patch(r + 1);
+    const int ks0 = (r * WK + wk) * 9;
+    // B fragments one tap ahead (xf[t & 1]), weights three taps ahead; the sched_barrier after every
+    // tap keeps the compiler from sinking those prefetches back down to their first use
+    f16x8 xh[2][2], xl[2][2];
+    auto load_x = [&](f16x8 (&dh)[2], f16x8 (&dl)[2], int t, int toff) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int a = ((vmask[ct] >> t) & 1u) ? rowb[ct] + toff : zrow;
+        dh[ct] = *reinterpret_cast<const f16x8*>(cur + a);
+        dl[ct] = *reinterpret_cast<const f16x8*>(cur + a + 32);
+      }
+    };
+    int toff = 0;                            // ((t / 3) * W + t % 3) * ROWB, built incrementally
+    load_x(xh[0], xl[0], 0, 0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      toff += (t % 3 == 2) ? (p.W - 2) * ROWB : ROWB;
+      if (t + 1 < 9) load_x(xh[(t + 1) & 1], xl[(t + 1) & 1], t + 1, toff);
+      // three independent sweeps over the tiles: no MFMA waits on the one issued just before it
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t % 3][rt], xh[t & 1][ct], accs[rt][ct], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t % 3][rt], xh[t & 1][ct], accm[rt][ct], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t % 3][rt], xl[t & 1][ct], accs[rt][ct], 0, 0, 0);
+      // tap t+3 of this round, or tap t-6 of the next one (same set either way)
+      load_w(wh[t % 3], wl[t % 3], t + 3 < 9 ? ks0 + t + 3 : ks0 + 9 * WK + t - 6);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!DB) __syncthreads();                // single buffer: everyone is done reading it
+    if (more) store_patch(nxt);
+    __syncthreads();
+  }
+
+  // ---- K-split waves: partial sums -> LDS, added by wave wk == 0 in fixed order
+  if (WK > 1) {
+    float* red = reinterpret_cast<float*>(smem);     // [wave][rt][ct][16][64]
+    if (wk > 0) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            red[(((wave * RT + rt) * 2 + ct) * 16 + r) * 64 + lane] = accm[rt][ct][r] + accs[rt][ct][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s = accm[rt][ct][r] + accs[rt][ct][r];
+#pragma unroll
+          for (int k = 1; k < WK; ++k) s += red[((((wave + k) * RT + rt) * 2 + ct) * 16 + r) * 64 + lane];
+          accm[rt][ct][r] = s;
+          accs[rt][ct][r] = 0.0f;
+        }
+  }
+
+  // ---- epilogue: lane = pixel, register group g = 4 consecutive channels
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int m = m0 + wp * 64 + ct * 32 + li;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = (rt0 + rt) * 32 + 8 * g + 4 * h;
+        if (n >= p.N) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
+        if (n + 3 < p.N) {
+          v += *reinterpret_cast<const f32x4*>(p.bias + n);
+          if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.res_stride + n);
+          if (p.act == CF_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+          }
+          *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.out_stride + n) = v;
+        } else {
+          for (int e = 0; e < 4 && n + e < p.N; ++e) {
+            float x = v[e] + p.bias[n + e];
+            if (p.residual) x += p.residual[(size_t)m * p.res_stride + n + e];
+            if (p.act == CF_ACT_RELU) x = fmaxf(x, 0.0f);
+            p.out[(size_t)m * p.out_stride + n + e] = x;
+          }
+        }
+      }
+  }
+}
+
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB>
+bool try_launch(const Conv3F& k, hipStream_t st) {
+  constexpr int R = 64 * WP, ROWB = 64 * WK + 16;
+  const long units = (long)k.PR * 4 * WK;
+  if (units > 256L * NU) return false;
+  size_t dyn = (size_t)(DB ? 2 : 1) * (k.PR + 1) * ROWB;
+  if (WK > 1) dyn = dyn < (size_t)4 * RT * 2 * 16 * 64 * 4 ? (size_t)4 * RT * 2 * 16 * 64 * 4 : dyn;
+  if (dyn > 160 * 1024) return false;
+  auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB>;
+  static size_t limit = 0;
+  if (dyn > limit) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(dyn < 65536 ? 65536 : dyn));
+    limit = dyn < 65536 ? 65536 : dyn;
+  }
+  const dim3 grid((unsigned)((k.M + R - 1) / R), (unsigned)((k.n_rt + WC * RT - 1) / (WC * RT)));
+  hipLaunchKernelGGL(kernel, grid, dim3(256), dyn, st, k);
+  return true;
+}
+
+}  // namespace
+
+// A geometry that fits no patch configuration is forwarded to cf_conv2d_f16x3 (same packed weights).
+extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
+  CF_REQUIRE(a != nullptr, "cf_conv3x3_f16x3: null args");
+  CF_REQUIRE(a->n_src == 1 && a->src[0] && a->src_c[0] > 0 && a->src_c[0] % 4 == 0, "cf_conv3x3_f16x3: one fp32 NHWC source");
+  CF_REQUIRE(a->stride == 1 && a->Ho == a->H && a->Wo == a->W, "cf_conv3x3_f16x3: stride 1, pad 1 only");
+  CF_REQUIRE(a->K_pad > 0 && a->K_pad % 32 == 0, "cf_conv3x3_f16x3: K_pad=%d not a multiple of 32", a->K_pad);
+  CF_REQUIRE(a->N > 0 && a->N_pad >= a->N && (a->N_pad == 32 || a->N_pad % 64 == 0), "cf_conv3x3_f16x3: N=%d N_pad=%d", a->N, a->N_pad);
+  CF_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "cf_conv3x3_f16x3: bad geometry");
+  CF_REQUIRE(a->weight && a->bias && a->out, "cf_conv3x3_f16x3: null buffer");
+  CF_REQUIRE(a->out_layout == CF_LAYOUT_NHWC && a->out_stride >= a->N && a->out_stride % 4 == 0,
+             "cf_conv3x3_f16x3: output must be fp32 NHWC with a stride that is a multiple of 4");
+  CF_REQUIRE(a->act == CF_ACT_NONE || a->act == CF_ACT_RELU, "cf_conv3x3_f16x3: act=%d unsupported", a->act);
+  CF_REQUIRE(a->out_scale > 0.0f, "cf_conv3x3_f16x3: out_scale must be the 2^-(s+4) the weights were packed with");
+  CF_REQUIRE(!a->residual || a->res_stride % 4 == 0, "cf_conv3x3_f16x3: residual stride must be a multiple of 4");
+  // K_pad = 16 * 9 * slices, rounded up to a multiple of 32
+  const int slices = a->K_pad / 144;
+  CF_REQUIRE(slices >= 1 && (a->K_pad == slices * 144 || a->K_pad == slices * 144 + 16),
+             "cf_conv3x3_f16x3: K_pad=%d is not a slice-major 3x3 packing", a->K_pad);
+  CF_REQUIRE(slices * 16 <= a->src_c[0], "cf_conv3x3_f16x3: %d input channels exceed the source width %d", slices * 16, a->src_c[0]);
+  const long M = (long)a->B * a->H * a->W;
+  CF_REQUIRE(M * a->src_c[0] < (1L << 31) && M < (1L << 31), "cf_conv3x3_f16x3: tensor too large");
+  Conv3F k{};
+  k.x = a->src[0];
+  k.weight = reinterpret_cast<const unsigned char*>(a->weight);
+  k.bias = a->bias; k.residual = a->residual; k.out = a->out;
+  k.x_stride = a->src_c[0];
+  k.H = a->H; k.W = a->W; k.HW = a->H * a->W; k.M = (int)M; k.N = a->N;
+  k.n_rt = a->N_pad / 32; k.n_ks = a->K_pad / 16;
+  k.res_stride = a->res_stride; k.out_stride = a->out_stride; k.act = a->act;
+  k.out_scale = a->out_scale;
+  hipStream_t st = (hipStream_t)stream;
+  bool ok = false;
+  auto cfg = [&](int R, int WK) {
+    k.PR = R + 2 * a->W + 2;
+    k.n_rounds = slices / WK;
+    return slices % WK == 0;
+  };
+  if (a->N_pad == 32) {
+    // (the choice must not depend on the batch size: WK changes the summation order, and a shard of a
+    //  batch has to reproduce the full batch bit for bit)
+    if ((long)a->H * a->W >= 4096 && cfg(256, 1)) {
+      ok = try_launch<1, 4, 1, 1, 8, true, 2>(k, st) || try_launch<1, 4, 1, 1, 12, true, 1>(k, st);
+    } else {
+      if (cfg(64, 4)) ok = try_launch<1, 1, 4, 1, 8, true, 2>(k, st) || try_launch<1, 1, 4, 1, 12, true, 2>(k, st);
+      if (!ok && cfg(128, 2)) ok = try_launch<1, 2, 2, 1, 12, true, 2>(k, st);
+      if (!ok && cfg(256, 1)) ok = try_launch<1, 4, 1, 1, 12, true, 1>(k, st);
+    }
+  } else if (a->N_pad == 64) {
+    if (cfg(256, 1)) ok = try_launch<1, 4, 1, 2, 6, true, 2>(k, st);
+  } else if (a->N_pad == 128) {
+    if (cfg(128, 1)) ok = try_launch<2, 2, 1, 2, 6, true, 2>(k, st);
+  } else {
+    if (cfg(64, 1)) ok = try_launch<4, 1, 1, 2, 4, true, 2>(k, st);
+  }
+  if (!ok) return cf_conv2d_f16x3(a, stream);
+  return cf_check_launch("cf_conv3x3_f16x3");
+}

@@ -21,15 +21,9 @@
 // per 32-deep chunk.  Workgroup = 4 waves as WC (channel groups) x WP (pixel groups); a wave owns
 // RT*32 output channels x 64 pixels.  Accumulators have pixels on lanes and 4 consecutive channels
 // per register group, so the fp32 NHWC store is one 16-byte write per lane and group.
-#include "cf_common.h"
+#include "cf_f16x3.h"
 
 namespace {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr float ASCALE = 16.0f;   // activation pre-scale (2^4), undone by out_scale
-constexpr int FROWB = 80;         // LDS bytes per pixel row per plane: 32 f16 + 16 B pad
 
 struct ConvF {
   const float* src[CF_MAX_SRC];
@@ -42,31 +36,6 @@ struct ConvF {
   int H, W, Ho, Wo, stride, n_chunks, res_stride, out_stride, act, M, N, HoWo, n_rt;
   float out_scale;
 };
-
-__device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
-  return ((unsigned)__builtin_bit_cast(unsigned short, b) << 16) | __builtin_bit_cast(unsigned short, a);
-}
-
-// 8 fp32 -> scaled, clamped, split into fp16 hi / lo (4 dwords each)
-__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4& hi, u32x4& lo) {
-  _Float16 h[8], l[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float x = (e < 4 ? v0[e] : v1[e - 4]) * ASCALE;
-    x = fminf(fmaxf(x, -65504.0f), 65504.0f);
-    h[e] = (_Float16)x;
-    l[e] = (_Float16)(x - (float)h[e]);
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    hi[e] = pack_h2(h[2 * e], h[2 * e + 1]);
-    lo[e] = pack_h2(l[2 * e], l[2 * e + 1]);
-  }
-}
-
-__device__ __forceinline__ const f16x8* wfrag16(const unsigned char* w, int rt, int ks, int plane, int n_ks, int lane) {
-  return reinterpret_cast<const f16x8*>(w + ((((size_t)rt * n_ks + ks) * 2 + plane) * 64 + lane) * 16);
-}
 
 // DB: double-buffered pixel tile (one barrier per chunk).  The 256-pixel tile of the 64-channel
 // layers (WP = 4) is single-buffered (two barriers per chunk) so two workgroups still fit a CU.

@@ -83,9 +83,32 @@ __device__ __forceinline__ void store_hidden_tile(unsigned char* xt, const f32x1
       }
 }
 
+// pixel index inside a 64-pixel tile -> (image, pixel inside the image); false = outside
+struct FlatMap {       // 64 consecutive pixels of the flattened (B*H*W) index space
+  int m0, M, HW;
+  __device__ __forceinline__ bool operator()(int px, int& b, int& pix) const {
+    const int m = m0 + px;
+    if (m >= M) return false;
+    b = m / HW;
+    pix = m - b * HW;
+    return true;
+  }
+};
+struct TileMap {       // rows [4 half, 4 half + 4) of an 8 x 16 tile at (y0, x0) of image b
+  int b, y0, x0, H, W;
+  __device__ __forceinline__ bool operator()(int px, int& bb, int& pix) const {
+    const int y = y0 + (px >> 4), x = x0 + (px & 15);
+    if (y >= H || x >= W) return false;
+    bb = b;
+    pix = y * W + x;
+    return true;
+  }
+};
+
 // 4 per-wave partial output tiles [32 n][64 px] -> LDS -> sum + bias + activation -> NCHW
+template <class PixMap>
 __device__ __forceinline__ void reduce_and_store(const HeadTailK& p, unsigned char* xt, const f32x16 (&oacc)[2],
-                                                 int head, int m0) {
+                                                 int head, const PixMap& pm) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   float* red = reinterpret_cast<float*>(xt);
@@ -102,9 +125,8 @@ __device__ __forceinline__ void reduce_and_store(const HeadTailK& p, unsigned ch
   float* out = p.out[head];
   float* out2 = p.out2[head];
   const int px = tid & 63;
-  const int m = m0 + px;
-  if (m < p.M) {
-    const int b = m / p.HW, pix = m - b * p.HW;
+  int b, pix;
+  if (pm(px, b, pix)) {
     for (int n = tid >> 6; n < n_out; n += 4) {
       const float raw = red[n * HT_PX + px] + red[(32 + n) * HT_PX + px] + red[(64 + n) * HT_PX + px] +
                         red[(96 + n) * HT_PX + px] + bo[n];
@@ -119,7 +141,8 @@ __device__ __forceinline__ void reduce_and_store(const HeadTailK& p, unsigned ch
 }
 
 // Hidden layers + output layer on a pixel tile that is already in LDS (xt).  All 256 threads.
-__device__ __forceinline__ void head_tail_from_lds(const HeadTailK& p, unsigned char* xt, int head, int m0) {
+template <class PixMap>
+__device__ __forceinline__ void head_tail_from_lds(const HeadTailK& p, unsigned char* xt, int head, const PixMap& pm) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
 
@@ -134,22 +157,17 @@ __device__ __forceinline__ void head_tail_from_lds(const HeadTailK& p, unsigned 
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    bf16x8 wh[2][2], wl[2][2];  // [buffer][rt]
+    bf16x8 wh[3][2], wl[3][2];  // [set = ks % 3][rt]: three k-steps ahead
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      wh[0][rt] = *wfrag(w, wave * 2 + rt, 0, 0, 16, lane);
-      wl[0][rt] = *wfrag(w, wave * 2 + rt, 0, 1, 16, lane);
-    }
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        wh[t][rt] = *wfrag(w, wave * 2 + rt, t, 0, 16, lane);
+        wl[t][rt] = *wfrag(w, wave * 2 + rt, t, 1, 16, lane);
+      }
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks + 1 < 16) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          wh[nxt][rt] = *wfrag(w, wave * 2 + rt, ks + 1, 0, 16, lane);
-          wl[nxt][rt] = *wfrag(w, wave * 2 + rt, ks + 1, 1, 16, lane);
-        }
-      }
+      const int cur = ks % 3;
       bf16x8 xh[2], xl[2];
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
@@ -165,6 +183,14 @@ __device__ __forceinline__ void head_tail_from_lds(const HeadTailK& p, unsigned 
           acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cur][rt], xl[ct], acc[rt][ct], 0, 0, 0);
           acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[cur][rt], xh[ct], acc[rt][ct], 0, 0, 0);
         }
+      if (ks + 3 < 16) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          wh[cur][rt] = *wfrag(w, wave * 2 + rt, ks + 3, 0, 16, lane);
+          wl[cur][rt] = *wfrag(w, wave * 2 + rt, ks + 3, 1, 16, lane);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the look-ahead loads from sinking to their first use
     }
     __syncthreads();  // every wave has read the whole tile: rewrite it in place
     store_hidden_tile(xt, acc, bias, wave, li, h);
@@ -195,7 +221,7 @@ __device__ __forceinline__ void head_tail_from_lds(const HeadTailK& p, unsigned 
     }
   }
   __syncthreads();  // tile no longer needed: reuse LDS for the 4 partial sums [wave][n 32][px 64]
-  reduce_and_store(p, xt, oacc, head, m0);
+  reduce_and_store(p, xt, oacc, head, pm);
 }
 
 // Tail only: the 256-channel hidden tile comes from a split-bf16 tensor in HBM.
@@ -228,7 +254,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(HeadTailK p) {
       *reinterpret_cast<u32x4*>(xt + plane * HT_PLANE + px * HT_ROWB + unit * 16) = v[it];
     }
     __syncthreads();
-    head_tail_from_lds(p, xt, head, m0);
+    head_tail_from_lds(p, xt, head, FlatMap{m0, p.M, p.HW});
     return;
   }
   // no hidden layer: the B fragments (pixels x this wave's 64 input channels) come straight from
@@ -262,7 +288,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(HeadTailK p) {
       oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[ct][s], oacc[ct], 0, 0, 0);
     }
   }
-  reduce_and_store(p, xt, oacc, head, m0);
+  reduce_and_store(p, xt, oacc, head, FlatMap{m0, p.M, p.HW});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -285,6 +311,8 @@ struct HeadFusedK {
 constexpr int HF_ROWB = 80;                       // 32 bf16 + 16 B pad per pixel row per plane
 constexpr int HF_PLANE = HT_PX * HF_ROWB;         // 5120
 constexpr int HF_BUF = 2 * HF_PLANE;              // 10240 per chunk buffer
+constexpr int HF_MAX_CHUNKS = 64;
+constexpr int HF_LDS = HT_LDS + HF_MAX_CHUNKS * 4 * (int)sizeof(cf_slot);   // tile area + slot table
 
 __global__ __launch_bounds__(256) void head_fused_kernel(HeadFusedK q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xt[];  // B chunk buffers, later the hidden tile
@@ -313,10 +341,15 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadFusedK q) {
       boff = 0;
     }
   }
+  // slot table -> LDS (behind the tile area): a per-chunk global read of it would put a dependent
+  // L2 round trip (and a vmcnt(0) drain of the weight prefetches) in front of every staging load
+  cf_slot* lds_slots = reinterpret_cast<cf_slot*>(xt + HT_LDS);
+  for (int i = tid; i < q.n_chunks * 4; i += 256) lds_slots[i] = q.slots[i];
+  __syncthreads();
   u32x4 sh, sl;
   auto load_b = [&](int c) {
-    const cf_slot s = q.slots[c * 4 + su];
-    const int src = __builtin_amdgcn_readfirstlane(q.slots[c * 4].src);
+    const cf_slot s = lds_slots[c * 4 + su];
+    const int src = __builtin_amdgcn_readfirstlane(lds_slots[c * 4].src);
     const unsigned char* sp = src == 1 ? q.src[1] : q.src[0];
     const int sc = src == 1 ? q.src_c[1] : q.src_c[0];
     const int y = y0 + s.dy, x = x0 + s.dx;
@@ -377,34 +410,272 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadFusedK q) {
   store_b(xt);
   load_b(1);
   __syncthreads();
-  // two chunks (four k-steps) per iteration so the four fragment sets are addressed statically
+  // two chunks (four k-steps) per iteration so the four fragment sets are addressed statically.
+  // Straight-line body (look-ahead indices clamped, not branched) with a sched_barrier after every
+  // k-step: without it the compiler sinks the prefetch loads down to their first use.
+  const int last_c = q.n_chunks - 1;
   for (int c = 0; c < q.n_chunks; c += 2) {
     unsigned char* b0 = xt;
     unsigned char* b1 = xt + HF_BUF;
     const int ks = c * 2;
     // chunk c  (buffer 0)
     mma_kstep(b0, 0, wh[0], wl[0]);
-    if (ks + 4 < n_ks) load_w(wh[0], wl[0], ks + 4);
+    load_w(wh[0], wl[0], min(ks + 4, n_ks - 1));
+    __builtin_amdgcn_sched_barrier(0);
     mma_kstep(b0, 1, wh[1], wl[1]);
-    if (ks + 5 < n_ks) load_w(wh[1], wl[1], ks + 5);
+    load_w(wh[1], wl[1], min(ks + 5, n_ks - 1));
     store_b(b1);                       // chunk c+1 (requested a chunk ago)
-    if (c + 2 < q.n_chunks) load_b(c + 2);
+    load_b(min(c + 2, last_c));
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     // chunk c+1 (buffer 1)
     mma_kstep(b1, 0, wh[2], wl[2]);
-    if (ks + 6 < n_ks) load_w(wh[2], wl[2], ks + 6);
+    load_w(wh[2], wl[2], min(ks + 6, n_ks - 1));
+    __builtin_amdgcn_sched_barrier(0);
     mma_kstep(b1, 1, wh[3], wl[3]);
-    if (ks + 7 < n_ks) load_w(wh[3], wl[3], ks + 7);
-    if (c + 2 < q.n_chunks) {
-      store_b(b0);                     // chunk c+2
-      if (c + 3 < q.n_chunks) load_b(c + 3);
-    }
+    load_w(wh[3], wl[3], min(ks + 7, n_ks - 1));
+    store_b(b0);                       // chunk c+2 (a repeat of the last chunk at the end: never read)
+    load_b(min(c + 3, last_c));
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
   // hidden = ReLU(acc + b) -> LDS tile (the staging buffers are dead: last barrier above)
   store_hidden_tile(xt, acc, q.b_first[head], wave, li, h);
   __syncthreads();
-  head_tail_from_lds(p, xt, head, m0);
+  head_tail_from_lds(p, xt, head, FlatMap{m0, p.M, p.HW});
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Whole head with n_hidden == 0 on a 2-D PATCH: one workgroup owns an 8 x 16 pixel tile (128 px) of
+// one image and one head.  The (8+2) x (16+2) input patch - all 64 feature channels (and the 8-channel
+// pc_hm plane pair) in split-bf16 - is copied to LDS once, zero-filled outside the image, and all 9
+// taps x 4 slices read their B fragments from it at compile-time offsets: no slot table, no barrier
+// and no staging inside the K loop.  A wave owns 64 hidden channels x 128 pixels, so the first-layer
+// weights (the dominant L2 stream of the 64-pixel kernel above) are fetched once per 128 pixels.
+// The 256 -> n_out layer runs straight from the accumulator registers: ReLU(acc + b) split to bf16 IS
+// a B fragment if the output weights are packed with the matching k permutation (w_out_perm: position
+// 8h + j of a 16-group holds channel 4h + (j & 3) + 8(j >> 2)); the four waves' partial sums meet in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int HP_TH = 8, HP_TW = 16, HP_PW = HP_TW + 2, HP_ROWS = (HP_TH + 2) * HP_PW;   // 180 patch rows
+constexpr int HP_PX = HP_TH * HP_TW;                                                    // 128
+constexpr int HP_RED = 4 * 32 * HP_PX * 4;                                              // 64 KiB of partial sums
+constexpr int HP_LDS = HT_LDS > HP_RED ? HT_LDS : HP_RED;   // patch (<= 55 KiB) / partial sums / 64-pixel hidden tile
+
+struct HeadPatchK {
+  HeadTailK t;
+  const unsigned char* src[2];
+  int src_c[2];
+  int H, W, tiles_x, tiles_y, n_ks;
+  const unsigned char* w_first[CF_MAX_HEADS];
+  const float* b_first[CF_MAX_HEADS];
+  const unsigned char* w_out_perm[CF_MAX_HEADS];
+};
+
+template <int NS, bool PC>
+__global__ __launch_bounds__(256, 2) void head_patch_kernel(HeadPatchK q) {
+  constexpr int ROWB = NS * 64 + (PC ? 32 : 0) + 16;     // odd multiple of 16 B
+  constexpr int NK = 9 * NS + (PC ? 5 : 0);              // k-steps of the first layer
+  extern __shared__ __attribute__((aligned(16))) unsigned char xt[];
+  const HeadTailK& p = q.t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int per_img = q.tiles_x * q.tiles_y;
+  const int per_head = per_img * (p.M / p.HW);
+  const int head = blockIdx.x / per_head;
+  int rem = blockIdx.x - head * per_head;
+  const int b = rem / per_img;
+  rem -= b * per_img;
+  const int y0 = (rem / q.tiles_x) * HP_TH, x0 = (rem % q.tiles_x) * HP_TW;
+  const unsigned char* w1 = q.w_first[head];
+
+  // ---- patch -> LDS (one pass, every load in flight before the first LDS write)
+  {
+    constexpr int UPR = NS * 4;                            // 16-byte units per row: hi plane then lo plane
+    constexpr int NIT = (HP_ROWS * UPR + 255) / 256;
+    u32x4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx / UPR, u = idx % UPR;
+      const int y = y0 - 1 + row / HP_PW, x = x0 - 1 + row % HP_PW;
+      v[it] = u32x4{0u, 0u, 0u, 0u};
+      if (row < HP_ROWS && (unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W)
+        v[it] = *reinterpret_cast<const u32x4*>(q.src[0] + ((size_t)(b * p.HW + y * q.W + x) * 2 * q.src_c[0]) * 2 +
+                                                (u / (NS * 2)) * q.src_c[0] * 2 + (u % (NS * 2)) * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx / UPR, u = idx % UPR;
+      const int plane = u / (NS * 2), uu = u % (NS * 2);
+      if (row < HP_ROWS) *reinterpret_cast<u32x4*>(xt + row * ROWB + (uu >> 1) * 64 + plane * 32 + (uu & 1) * 16) = v[it];
+    }
+    if (PC) {
+      for (int idx = tid; idx < HP_ROWS * 2; idx += 256) {
+        const int row = idx >> 1, plane = idx & 1;
+        const int y = y0 - 1 + row / HP_PW, x = x0 - 1 + row % HP_PW;
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if ((unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W)
+          w = *reinterpret_cast<const u32x4*>(q.src[1] + ((size_t)(b * p.HW + y * q.W + x) * 2 + plane) * q.src_c[1] * 2);
+        *reinterpret_cast<u32x4*>(xt + row * ROWB + NS * 64 + plane * 16) = w;
+      }
+    }
+  }
+
+  int rowb[4];                               // LDS byte offset of this lane's pixel row (tap (-1,-1)) + k half
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int pl = ct * 32 + li;
+    rowb[ct] = ((pl >> 4) * HP_PW + (pl & 15)) * ROWB + h * 16;
+  }
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.0f;
+
+  bf16x8 wh[3][2], wl[3][2];                 // weight fragments three k-steps ahead: set ks % 3
+  auto load_w = [&](bf16x8 (&dh)[2], bf16x8 (&dl)[2], int ks) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      dh[rt] = *wfrag(w1, wave * 2 + rt, ks, 0, q.n_ks, lane);
+      dl[rt] = *wfrag(w1, wave * 2 + rt, ks, 1, q.n_ks, lane);
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < 3; ++t) load_w(wh[t], wl[t], t);
+  __syncthreads();
+
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    bf16x8 xh[4], xl[4];
+    if (ks < 9 * NS) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int tap = ks / NS, sl = ks % NS;
+      const int off = ((tap / 3) * HP_PW + tap % 3) * ROWB + sl * 64;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        xh[ct] = *reinterpret_cast<const bf16x8*>(xt + rowb[ct] + off);
+        xl[ct] = *reinterpret_cast<const bf16x8*>(xt + rowb[ct] + off + 32);
+      }
+    } else {                                 // pc_hm: k half h of step i is tap 2i + h (8 channels each)
+      const int i = ks - 9 * NS;
+      const int t0 = 2 * i, t1 = 2 * i + 1 < 9 ? 2 * i + 1 : 8;
+      const int o0 = ((t0 / 3) * HP_PW + t0 % 3) * ROWB, o1 = ((t1 / 3) * HP_PW + t1 % 3) * ROWB;
+      const int off = (h ? o1 - 16 : o0) + NS * 64;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        xh[ct] = *reinterpret_cast<const bf16x8*>(xt + rowb[ct] + off);
+        xl[ct] = *reinterpret_cast<const bf16x8*>(xt + rowb[ct] + off + 16);
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[ks % 3][rt], xh[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks % 3][rt], xl[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[ks % 3][rt], xh[ct], acc[rt][ct], 0, 0, 0);
+    if (ks + 3 < NK) load_w(wh[ks % 3], wl[ks % 3], ks + 3);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  if (p.n_hidden > 0) {
+    // hidden layers need all 256 channels of a pixel: the two 64-pixel halves of the tile go through
+    // the LDS-resident chain of cf_head_tail one after the other (LDS stays at 66 KiB: 2 workgroups/CU)
+    __syncthreads();                         // every wave is done with the patch
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x16 a2[2][2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) a2[rt][ct] = acc[rt][2 * half + ct];
+      store_hidden_tile(xt, a2, q.b_first[head], wave, li, h);
+      __syncthreads();
+      head_tail_from_lds(p, xt, head, TileMap{b, y0 + 4 * half, x0, q.H, q.W});
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- output layer from registers: this wave's 64 hidden channels = 4 k-steps of 16
+  f32x16 oacc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[c][r] = 0.0f;
+  {
+    const float* b1 = q.b_first[head] + wave * 64 + 4 * h;
+    const unsigned char* wo = q.w_out_perm[head];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int ks2 = wave * 4 + rt * 2 + jj;
+        const bf16x8 ah = *wfrag(wo, 0, ks2, 0, 16, lane), al = *wfrag(wo, 0, ks2, 1, 16, lane);
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(b1 + rt * 32 + 16 * jj);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + rt * 32 + 16 * jj + 8);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          float v[8], hi[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] = fmaxf(acc[rt][ct][8 * jj + j] + (j < 4 ? ba[j] : bb[j - 4]), 0.0f);
+            hi[j] = bf16_rne(v[j]);
+          }
+          const u32x4 ph = {pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7])};
+          const u32x4 pl = {pack2(v[0] - hi[0], v[1] - hi[1]), pack2(v[2] - hi[2], v[3] - hi[3]),
+                            pack2(v[4] - hi[4], v[5] - hi[5]), pack2(v[6] - hi[6], v[7] - hi[7])};
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, ph), xl = __builtin_bit_cast(bf16x8, pl);
+          oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, oacc[ct], 0, 0, 0);
+          oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, oacc[ct], 0, 0, 0);
+          oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, oacc[ct], 0, 0, 0);
+        }
+      }
+  }
+  __syncthreads();                           // every wave is done with the patch: reuse LDS for the partial sums
+  const int n_out = p.n_out[head], act = p.act[head];
+  float* red = reinterpret_cast<float*>(xt); // [wave][n 32][px 128]
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (n < n_out) red[(wave * 32 + n) * HP_PX + ct * 32 + li] = oacc[ct][r];
+    }
+  __syncthreads();
+  {
+    const int px = tid & (HP_PX - 1);
+    const int y = y0 + (px >> 4), x = x0 + (px & 15);
+    if (y < q.H && x < q.W) {
+      const float* bo = p.b_out[head];
+      float* out = p.out[head];
+      float* out2 = p.out2[head];
+      for (int n = tid >> 7; n < n_out; n += 2) {
+        const float raw = red[n * HP_PX + px] + red[(32 + n) * HP_PX + px] + red[(64 + n) * HP_PX + px] +
+                          red[(96 + n) * HP_PX + px] + bo[n];
+        const size_t o = ((size_t)b * n_out + n) * p.HW + (size_t)y * q.W + x;
+        float v = raw;
+        if (act == CF_ACT_RELU) v = fmaxf(raw, 0.0f);
+        else if (act == CF_ACT_SIGMOID_CLAMP) v = fminf(fmaxf(cf_sigmoid(raw), 1e-4f), 1.0f - 1e-4f);
+        out[o] = v;
+        if (act == CF_ACT_RAW_AND_SIGDEPTH) out2[o] = 1.0f / (cf_sigmoid(raw) + 1e-6f) - 1.0f;
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -472,6 +743,7 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
     k.src_c[i] = a->src_c[i];
   }
   CF_REQUIRE(a->slots && a->K_pad > 0 && a->K_pad % 64 == 0, "cf_head_fused: K_pad=%d must be a multiple of 64", a->K_pad);
+  CF_REQUIRE(a->K_pad / 32 <= HF_MAX_CHUNKS, "cf_head_fused: K_pad=%d exceeds %d", a->K_pad, HF_MAX_CHUNKS * 32);
   k.slots = a->slots;
   k.n_chunks = a->K_pad / 32;
   k.H = a->tail.H;
@@ -481,13 +753,46 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
     k.w_first[i] = reinterpret_cast<const unsigned char*>(a->w_first[i]);
     k.b_first[i] = a->b_first[i];
   }
+  if (a->layout3x3 && a->src_c[0] == 64 && (a->n_src == 1 || a->src_c[1] == 8)) {
+    // 2-D patch kernel: K order = 9 taps x 64 feature channels [, then the pc_hm taps pairwise]
+    HeadPatchK hp{};
+    hp.t = k.t;
+    hp.src[0] = k.src[0]; hp.src[1] = k.src[1];
+    hp.src_c[0] = k.src_c[0]; hp.src_c[1] = k.src_c[1];
+    hp.H = k.H; hp.W = k.W;
+    hp.tiles_x = (k.W + HP_TW - 1) / HP_TW;
+    hp.tiles_y = (k.H + HP_TH - 1) / HP_TH;
+    hp.n_ks = a->K_pad / 16;
+    CF_REQUIRE(hp.n_ks >= (a->n_src == 2 ? 41 : 36), "cf_head_fused: K_pad=%d too small for the 3x3 layout", a->K_pad);
+    for (int i = 0; i < a->tail.n_heads; ++i) {
+      CF_REQUIRE(a->tail.n_hidden > 0 || a->w_out_perm[i], "cf_head_fused: head %d: w_out_perm missing", i);
+      hp.w_first[i] = k.w_first[i];
+      hp.b_first[i] = k.b_first[i];
+      hp.w_out_perm[i] = reinterpret_cast<const unsigned char*>(a->w_out_perm[i]);
+    }
+    const long blocks = (long)hp.tiles_x * hp.tiles_y * a->tail.B * a->tail.n_heads;
+    CF_REQUIRE(blocks < (1L << 31), "cf_head_fused: grid too large");
+    static bool patch_attr = false;
+    if (!patch_attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_patch_kernel<4, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, HP_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_patch_kernel<4, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, HP_LDS);
+      patch_attr = true;
+    }
+    if (a->n_src == 2)
+      hipLaunchKernelGGL((head_patch_kernel<4, true>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
+    else
+      hipLaunchKernelGGL((head_patch_kernel<4, false>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
+    return cf_check_launch("cf_head_fused");
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_fused_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, HT_LDS);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, HF_LDS);
     attr_set = true;
   }
   const int tiles = (k.t.M + HT_PX - 1) / HT_PX;
-  hipLaunchKernelGGL(head_fused_kernel, dim3(tiles * a->tail.n_heads), dim3(256), HT_LDS, (hipStream_t)stream, k);
+  hipLaunchKernelGGL(head_fused_kernel, dim3(tiles * a->tail.n_heads), dim3(256), HF_LDS, (hipStream_t)stream, k);
   return cf_check_launch("cf_head_fused");
 }

@@ -192,7 +192,9 @@ class _Plan:
             self.step_index[name] = len(self.steps)
             self.step_flops[name] = 2.0 * B * ho * wo * pc.n * (pc.kh * pc.kh * sum(
                 int(c) for c in pc.real_cin))
-            fn = self.lib.cf_conv2d_f16x3 if pc.out_scale > 0 else self.lib.cf_conv2d_fused
+            fn = self.lib.cf_conv2d_fused
+            if pc.out_scale > 0:
+                fn = self.lib.cf_conv3x3_f16x3 if (pc.patch and model.conv_patch) else self.lib.cf_conv2d_f16x3
             self.steps.append((fn, C.byref(a)))
             return out, a
 
@@ -488,6 +490,7 @@ class DLASeg(nn.Module):
         self._plans = {}
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
+        self.conv_patch = True   # 3x3 stride-1 f16x3 convs: LDS patch reuse (cf_conv3x3_f16.hip)
         self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)
         self.heads_fused = True  # with heads_bf16: one launch per head group, hidden maps stay in LDS
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
@@ -516,7 +519,9 @@ class DLASeg(nn.Module):
             """split-fp16 products (fp32 storage) wherever the sources allow 8-channel slots."""
             # (<= 32 output channels stay on the fp32 kernels: a 32-row MFMA tile per wave leaves the
             #  f16 path bound by the on-the-fly operand split)
-            if f16 and w.shape[0] > 32 and all(s.stride % 8 == 0 and s.channels % 8 == 0 for s in sources):
+            ok8 = all(s.stride % 8 == 0 and s.channels % 8 == 0 for s in sources)
+            patchable = (w.shape[2] == 3 and stride == 1 and len(sources) == 1 and sources[0].channels % 16 == 0)
+            if f16 and ok8 and (w.shape[0] > 32 or patchable):
                 return packing.pack_conv_f16(w, b, sources, stride=stride).to(device)
             return packing.pack_conv(w, b, sources, stride=stride).to(device)
 
@@ -603,6 +608,7 @@ class DLASeg(nn.Module):
                 return dict(w_hidden=[packing.pack_fragments(hw(h, i).view(256, 256)).to(device) for i in hidden_idx],
                             b_hidden=[hb(h, i).to(device) for i in hidden_idx],
                             w_out=packing.pack_fragments(hw(h, out_idx).view(n_out, 256)).to(device),
+                            w_out_perm=packing.pack_fragments(hw(h, out_idx).view(n_out, 256), acc_order=True).to(device),
                             b_out=b32.to(device), n_out=n_out)
             def first(h, srcs):
                 pc = packing.pack_conv_bf16(hw(h, 0), hb(h, 0), srcs, fragments=True).to(device)

@@ -46,12 +46,16 @@ def conv_args(pc: PackedConv, srcs: Sequence[torch.Tensor], src_strides: Sequenc
     return a
 
 
-def run_conv_f16(a: _lib.ConvArgs):
-    _lib.check(_lib.load().cf_conv2d_f16x3(C.byref(a), _lib.stream_ptr()), "cf_conv2d_f16x3")
+def run_conv_f16(a: _lib.ConvArgs, patch=False):
+    if patch:
+        _lib.check(_lib.load().cf_conv3x3_f16x3(C.byref(a), _lib.stream_ptr()), "cf_conv3x3_f16x3")
+    else:
+        _lib.check(_lib.load().cf_conv2d_f16x3(C.byref(a), _lib.stream_ptr()), "cf_conv2d_f16x3")
 
 
-def conv2d_f16x3(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, residual=None, out=None):
-    """fp32 NHWC in / out, split-fp16 products (packing.pack_conv_f16)."""
+def conv2d_f16x3(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, residual=None, out=None, patch=None):
+    """fp32 NHWC in / out, split-fp16 products (packing.pack_conv_f16).  patch: use the LDS-patch
+    3x3 kernel (default: whenever the packing allows it)."""
     _need_cuda(*srcs, residual)
     Ho = (H + 2 * pc.pad - pc.kh) // pc.stride + 1
     Wo = (W + 2 * pc.pad - pc.kh) // pc.stride + 1
@@ -59,7 +63,7 @@ def conv2d_f16x3(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, residual=None, out
         out = torch.empty((B, Ho, Wo, pc.n), device=srcs[0].device, dtype=torch.float32)
     a = conv_args(pc, srcs, [s.shape[-1] for s in srcs], B, H, W, out, out.shape[-1], act, residual,
                   residual.shape[-1] if residual is not None else 0, LAYOUT_NHWC, None, 0, False)
-    run_conv_f16(a)
+    run_conv_f16(a, pc.patch if patch is None else patch)
     return out
 
 
@@ -140,8 +144,10 @@ def head_tail_args(x, x_stride, B, H, W, heads):
     return a
 
 
-def head_fused_args(srcs, src_strides, slots, k_pad, B, H, W, heads):
-    """heads: as head_tail_args plus w_first (fragment-packed [8][K_pad/16]...) and b_first (256 f32)."""
+def head_fused_args(srcs, src_strides, slots, k_pad, B, H, W, heads, layout3x3=None):
+    """heads: as head_tail_args plus w_first (fragment-packed [8][K_pad/16]...) and b_first (256 f32).
+    layout3x3 (default: every head carries w_out_perm): the slots are pack_conv_bf16's canonical order for
+    [feat 64 (, pc_hm 8)] sources, so the 2-D patch kernel may take the launch."""
     f = _lib.HeadFusedArgs()
     t = head_tail_args(srcs[0], 256, B, H, W, [dict(hd, c_base=0) for hd in heads])
     C.memmove(C.byref(f.tail), C.byref(t), C.sizeof(t))
@@ -151,6 +157,9 @@ def head_fused_args(srcs, src_strides, slots, k_pad, B, H, W, heads):
     f.slots, f.K_pad = slots.data_ptr(), k_pad
     for i, hd in enumerate(heads):
         f.w_first[i], f.b_first[i] = hd["w_first"].data_ptr(), hd["b_first"].data_ptr()
+        if hd.get("w_out_perm") is not None:
+            f.w_out_perm[i] = hd["w_out_perm"].data_ptr()
+    f.layout3x3 = int(all(hd.get("w_out_perm") is not None for hd in heads)) if layout3x3 is None else int(layout3x3)
     return f
 
 

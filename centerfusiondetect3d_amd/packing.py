@@ -50,6 +50,7 @@ class PackedConv:
     pad: int
     real_cin: tuple = ()      # real input channels per source (for FLOP accounting)
     out_scale: float = 0.0    # cf_conv2d_f16x3: 2^-(s+4)
+    patch: bool = False       # slice-major 3x3 packing: cf_conv3x3_f16x3 may run it
 
     def to(self, device):
         self.weight = self.weight.to(device).contiguous()
@@ -144,13 +145,20 @@ def pack_conv_bf16(weight, bias, sources: Sequence[Source], stride=1, pad=None, 
 def pack_conv_f16(weight, bias, sources: Sequence[Source], stride=1, pad=None, dilation=1) -> PackedConv:
     """Packing for cf_conv2d_f16x3: fp32 NHWC sources, 8-channel slots (4 per 32-deep chunk), weights
     scaled by 2^s (max|w| -> [2^13, 2^14)), split into fp16 hi/lo and laid out in MFMA A-operand
-    fragment order.  PackedConv.out_scale = 2^-(s+4) undoes the weight and activation scales."""
+    fragment order.  PackedConv.out_scale = 2^-(s+4) undoes the weight and activation scales.
+
+    A 3x3 / stride 1 / pad 1 convolution of ONE source with C % 16 == 0 is packed SLICE-MAJOR
+    (k = (16-channel slice, tap, channel)): that is the order cf_conv3x3_f16x3 (LDS patch reuse)
+    consumes, and since the slot table spells the same order out the generic kernel runs the very same
+    weights (PackedConv.patch marks them)."""
     co, ci, kh, kw = weight.shape
     assert ci == sum(s.channels for s in sources), (ci, [s.channels for s in sources])
     pad = (kh - 1) // 2 * dilation if pad is None else pad
     n_pad = 32 if co <= 32 else ((co + 63) // 64) * 64
     slots, cols, c_lo = [], [], 0
-    for si, s in enumerate(sources):
+    patch = (kh == 3 and kw == 3 and stride == 1 and dilation == 1 and pad == 1 and len(sources) == 1
+             and sources[0].channels % 16 == 0 and sources[0].c_base == 0 and sources[0].stride % 8 == 0)
+    for si, s in enumerate(sources if not patch else ()):
         assert s.stride % 8 == 0 and s.c_base % 8 == 0 and s.channels % 8 == 0, "f16x3 sources need C % 8 == 0"
         n_slots = 0
         for r in range(kh):
@@ -164,6 +172,16 @@ def pack_conv_f16(weight, bias, sources: Sequence[Source], stride=1, pad=None, d
             cols.append((-1, 0, 0))
             n_slots += 1
         c_lo += s.channels
+    if patch:
+        for cs in range(sources[0].channels // 16):
+            for r in range(3):
+                for q in range(3):
+                    for g in range(2):
+                        slots.append([0, r - 1, q - 1, 16 * cs + 8 * g])
+                        cols.append((16 * cs + 8 * g, r, q))
+        while len(slots) % 4:
+            slots.append([0, 0, 0, -1])
+            cols.append((-1, 0, 0))
     k_pad = len(slots) * 8
     w = torch.zeros(n_pad, k_pad, dtype=torch.float64)
     wf = weight.double()
@@ -182,18 +200,25 @@ def pack_conv_f16(weight, bias, sources: Sequence[Source], stride=1, pad=None, d
     pc = PackedConv(f.view(n_pad // 32, k_pad // 16, 2, 64, 8), b, torch.tensor(slots, dtype=torch.int32),
                     co, n_pad, k_pad, kh, stride, pad, tuple(s.channels for s in sources))
     pc.out_scale = 2.0 ** -(s_exp + 4)
+    pc.patch = patch
     return pc
 
 
-def pack_fragments(weight2d, n_pad=None):
+def pack_fragments(weight2d, n_pad=None, acc_order=False):
     """(N, K) fp32 -> MFMA A-operand fragment order for cf_head_tail:
     uint8 view of [N_pad/32][K/16][2 (hi, lo)][64 lanes][8 bf16]; lane (i = l & 31, h = l >> 5)
-    holds W[32 rt + i][16 ks + 8 h + j], j = 0..7."""
+    holds W[32 rt + i][16 ks + 8 h + j], j = 0..7.
+    acc_order: position 8h + j of every 16-group holds channel 4h + (j & 3) + 8 (j >> 2) instead - the
+    order in which a 32x32 accumulator's register group presents its rows (cf_head_fused w_out_perm)."""
     n, k = weight2d.shape
     assert k % 16 == 0
     n_pad = n_pad or ((n + 31) // 32) * 32
     w = torch.zeros(n_pad, k)
     w[:n] = weight2d.float()
+    if acc_order:
+        perm = torch.tensor([16 * g + 4 * hh + (j & 3) + 8 * (j >> 2)
+                             for g in range(k // 16) for hh in range(2) for j in range(8)])
+        w = w[:, perm]
     hi = w.to(torch.bfloat16)
     lo = (w - hi.float()).to(torch.bfloat16)
     planes = torch.stack([hi, lo], 0)                                   # (2, N, K)

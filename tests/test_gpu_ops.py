@@ -404,11 +404,19 @@ def test_head_tail_fused_chain(dev, n_hidden, B, H, W):
             close(hd["out2"], 1.0 / (torch.sigmoid(raw) + 1e-6) - 1.0, 1e-3, 1e-3)
 
 
-@pytest.mark.parametrize("n_hidden,radar,B,H,W", [(0, False, 2, 9, 14), (2, True, 1, 16, 20), (1, True, 2, 7, 9)])
-def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W):
-    """3x3 conv (feat [|| pc_hm]) + ReLU -> hidden chain -> output, one launch, vs fp32 torch."""
+@pytest.mark.parametrize("n_hidden,radar,B,H,W,patch", [
+    (0, False, 2, 9, 14, False), (2, True, 1, 16, 20, False), (1, True, 2, 7, 9, False),
+    (0, False, 2, 9, 14, True),       # 2-D patch kernel: one partial 8x16 tile per image
+    (0, True, 1, 21, 37, True),       # ... with the pc_hm taps, ragged tiles in both directions
+    (0, False, 3, 16, 32, True),      # ... exact tiling
+    (2, True, 2, 13, 19, True),       # hidden layers behind the patch first layer (two 64-pixel halves)
+    (1, False, 1, 8, 40, True),
+])
+def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W, patch):
+    """3x3 conv (feat [|| pc_hm]) + ReLU -> hidden chain -> output, one launch, vs fp32 torch.
+    patch: heads without hidden layers on the 2-D LDS-patch kernel (w_out_perm given)."""
     from centerfusiondetect3d_amd import ops, packing
-    n_outs, acts = [10, 1, 3], [2, 3, 0]
+    n_outs, acts = [10, 1, 3, 8], [2, 3, 0, 0]
     feat, pch = rnd(B, 64, H, W, seed=1), rnd(B, 3, H, W, seed=2)
     srcs = [_split(feat, dev)] + ([_split(pch, dev, cs=8)] if radar else [])
     sources = [packing.Source(64, 64)] + ([packing.Source(3, 8)] if radar else [])
@@ -432,9 +440,11 @@ def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W):
         out2 = torch.full((B, no, H, W), float("nan"), device=dev) if act == 3 else None
         heads.append(dict(w_first=pc.weight, b_first=pc.bias[:256].contiguous(), w_hidden=wh, b_hidden=bh,
                           w_out=packing.pack_fragments(w.view(no, 256)).to(dev), b_out=b32.to(dev),
+                          w_out_perm=packing.pack_fragments(w.view(no, 256), acc_order=True).to(dev) if patch else None,
                           n_out=no, act=act, out=out, out2=out2))
         refs.append(raw)
     f = ops.head_fused_args(srcs, [s.shape[-1] for s in srcs], slots, k_pad, B, H, W, heads)
+    assert f.layout3x3 == int(patch)
     ops.run_head_fused(f)
     for hd, raw in zip(heads, refs):
         scale = float(raw.abs().max())
@@ -502,6 +512,48 @@ def test_conv2d_f16x3_fp32_level_accuracy(dev, B, Ci, Co, H, W, k, stride, act, 
     err32 = float((ref32.double() - ref).abs().max() / ref.abs().max())
     print(f"[f16x3] K={Ci * k * k}: max|err|/max|ref| = {err:.2e} (torch fp32 conv: {err32:.2e})")
     assert err < 1.5e-6, err
+
+
+@pytest.mark.parametrize("B,Ci,Co,H,W,act,res,exact", [
+    (3, 64, 27, 23, 31, 0, False, False),     # conv_offset_mask, small map: K split over the 4 waves
+    (16, 64, 27, 112, 200, 0, False, True),   # conv_offset_mask at the bench size: 256-pixel runs
+    (2, 512, 27, 14, 25, 0, False, False),    # ida_0.proj_1 offsets: 32 slices, WK = 4
+    (2, 96, 27, 20, 30, 0, False, False),     # 6 slices: WK = 2
+    (2, 48, 27, 9, 11, 0, False, True),       # 3 slices (odd k-step count, padded K): WK = 1
+    (1, 64, 64, 28, 50, 1, True, True),       # level2 block conv2 + residual
+    (2, 128, 128, 30, 26, 1, False, True),    # level3
+    (2, 256, 256, 14, 25, 1, True, True),     # level4
+    (1, 512, 512, 7, 13, 1, False, True),     # level5: two channel blocks
+    (1, 64, 64, 5, 300, 1, False, True),      # too wide for the LDS patch: forwarded to the slot kernel
+    (2, 16, 27, 1, 7, 0, False, True),        # single-row image (every dy != 0 tap is outside)
+])
+def test_conv3x3_f16x3_patch(dev, B, Ci, Co, H, W, act, res, exact):
+    """LDS-patch 3x3 kernel: fp32-level accuracy against float64, and - where the K loop is not split
+    over waves - the very same bits as the generic slot kernel run on the same packed weights."""
+    from centerfusiondetect3d_amd import ops, packing
+    x, w, b = F.relu(rnd(B, Ci, H, W, seed=1)) * 3, rnd(Co, Ci, 3, 3, seed=2, scale=(Ci * 9) ** -0.5), rnd(Co, seed=3)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    r = rnd(*ref.shape, seed=6) if res else None
+    if res:
+        ref = ref + r.double()
+    if act:
+        ref = F.relu(ref)
+    pc = packing.pack_conv_f16(w, b, [packing.Source(Ci, Ci)]).to(dev)
+    assert pc.patch
+    stride_out = 32 if Co == 27 else Co
+    xd, rd = nhwc(x).to(dev), (nhwc(r).to(dev) if res else None)
+    out = torch.full((B, H, W, stride_out), float("nan"), device=dev)
+    ops.conv2d_f16x3(pc, [xd], B, H, W, act=act, residual=rd, out=out, patch=True)
+    got = nchw(out[..., :Co]).cpu().double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print(f"[conv3x3 patch] {Ci}->{Co} {H}x{W}: max|err|/max|ref| = {err:.2e}")
+    assert err < 1.5e-6, err
+    if Co == 27:
+        assert torch.isnan(out[..., 27:]).all()          # the padding channels are never written
+    if exact:
+        out2 = torch.zeros_like(out)
+        ops.conv2d_f16x3(pc, [xd], B, H, W, act=act, residual=rd, out=out2, patch=False)
+        assert torch.equal(out[..., :Co], out2[..., :Co])
 
 
 def test_conv2d_f16x3_root_concat(dev):
