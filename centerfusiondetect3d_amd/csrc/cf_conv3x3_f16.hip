@@ -31,13 +31,19 @@ struct Conv3F {
   const float* residual;
   float* out;
   int x_stride, H, W, HW, M, N, n_rt, n_ks, n_rounds, res_stride, out_stride, act, PR;
+  int tiles_x, tiles_y;         // T2 only
   float out_scale;
 };
 
-template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB>
+// T2: the R pixels are an (R/16) x 16 tile of ONE image instead of a flat run: the patch is the tile
+// plus a one-pixel frame, (R/16 + 2) x 18 rows, zero-filled outside the image - so no tap needs a
+// validity select and the tap offsets are compile-time constants.  Pays on wide maps (W = 200: 1.3x
+// input traffic instead of 2.6x) whenever W is close to a multiple of 16.
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2>
 __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
   static_assert(WC * WP * WK == 4, "4 waves per workgroup");
   constexpr int R = 64 * WP;
+  constexpr int PW2 = 18;                   // T2: patch width (16 + 2)
   constexpr int ROWB = 64 * WK + 16;        // per patch row: WK x (16 hi + 16 lo f16) + pad (odd multiple of 16 B)
   constexpr int UPR = 4 * WK;               // 16-byte fp32 units per patch row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -45,7 +51,15 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int wk = wave % WK, wp = (wave / WK) % WP, wc = wave / (WK * WP);
-  const int m0 = blockIdx.x * R;
+  int m0 = blockIdx.x * R;                  // flat: first pixel; T2: first pixel of the image + tile origin below
+  int ty0 = 0, tx0 = 0;
+  if (T2) {
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int b = blockIdx.x / per_img, rem = blockIdx.x - b * per_img;
+    ty0 = (rem / p.tiles_x) * (R / 16);
+    tx0 = (rem % p.tiles_x) * 16;
+    m0 = b * p.HW;
+  }
   const int rt0 = (blockIdx.y * WC + wc) * RT;
   const bool w_ok = rt0 < p.n_rt;
   const int bufb = (p.PR + 1) * ROWB;       // + the zero row
@@ -63,8 +77,14 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
   for (int it = 0; it < NU; ++it) {
     const int u = tid + 256 * it;
     const int row = u / UPR, q = u % UPR;
-    const int g = m0 - p.W - 1 + row;
-    goff[it] = (row < p.PR && g >= 0 && g < p.M) ? g * p.x_stride + 4 * q : -1;
+    if (T2) {
+      const int y = ty0 - 1 + row / PW2, x = tx0 - 1 + row % PW2;
+      const bool ok = row < p.PR && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      goff[it] = ok ? (m0 + y * p.W + x) * p.x_stride + 4 * q : -1;
+    } else {
+      const int g = m0 - p.W - 1 + row;
+      goff[it] = (row < p.PR && g >= 0 && g < p.M) ? g * p.x_stride + 4 * q : -1;
+    }
   }
   f32x4 raw[NU];
   auto load_patch = [&](int r) {
@@ -102,9 +122,11 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
   for (int ct = 0; ct < 2; ++ct) {
     const int pl = wp * 64 + ct * 32 + li;
     const int m = m0 + pl;
-    rowb[ct] = pl * ROWB + wk * 64 + h * 16;
+    rowb[ct] = (T2 ? (pl >> 4) * PW2 + (pl & 15) : pl) * ROWB + wk * 64 + h * 16;
     unsigned mk = 0;
-    if (m < p.M) {
+    if (T2) {
+      mk = 0x1ffu;                           // the frame is part of the patch
+    } else if (m < p.M) {
       const int rem = m % p.HW;
       const int y = rem / p.W, x = rem - y * p.W;
 #pragma unroll
@@ -157,7 +179,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
     auto load_x = [&](f16x8 (&dh)[2], f16x8 (&dl)[2], int t, int toff) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        const int a = ((vmask[ct] >> t) & 1u) ? rowb[ct] + toff : zrow;
+        const int a = (T2 || ((vmask[ct] >> t) & 1u)) ? rowb[ct] + toff : zrow;
         dh[ct] = *reinterpret_cast<const f16x8*>(cur + a);
         dl[ct] = *reinterpret_cast<const f16x8*>(cur + a + 32);
       }
@@ -166,7 +188,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
     load_x(xh[0], xl[0], 0, 0);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      toff += (t % 3 == 2) ? (p.W - 2) * ROWB : ROWB;
+      toff += (t % 3 == 2) ? ((T2 ? PW2 : p.W) - 2) * ROWB : ROWB;
       if (t + 1 < 9) load_x(xh[(t + 1) & 1], xl[(t + 1) & 1], t + 1, toff);
       // three independent sweeps over the tiles: no MFMA waits on the one issued just before it
 #pragma unroll
@@ -224,8 +246,15 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
   // ---- epilogue: lane = pixel, register group g = 4 consecutive channels
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
-    const int m = m0 + wp * 64 + ct * 32 + li;
-    if (m >= p.M) continue;
+    const int pl = wp * 64 + ct * 32 + li;
+    int m = m0 + pl;
+    if (T2) {
+      const int y = ty0 + (pl >> 4), x = tx0 + (pl & 15);
+      if (y >= p.H || x >= p.W) continue;
+      m = m0 + y * p.W + x;
+    } else if (m >= p.M) {
+      continue;
+    }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -255,24 +284,40 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
   }
 }
 
-template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB>
-bool try_launch(const Conv3F& k, hipStream_t st) {
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2 = false>
+bool try_launch(Conv3F k, int batch, hipStream_t st) {
   constexpr int R = 64 * WP, ROWB = 64 * WK + 16;
+  long blocks;
+  if (T2) {
+    k.PR = (R / 16 + 2) * 18;
+    k.tiles_x = (k.W + 15) / 16;
+    k.tiles_y = (k.H + R / 16 - 1) / (R / 16);
+    blocks = (long)k.tiles_x * k.tiles_y * batch;
+  } else {
+    k.PR = R + 2 * k.W + 2;
+    blocks = (k.M + R - 1) / R;
+  }
   const long units = (long)k.PR * 4 * WK;
-  if (units > 256L * NU) return false;
+  if (units > 256L * NU || blocks >= (1L << 31)) return false;
   size_t dyn = (size_t)(DB ? 2 : 1) * (k.PR + 1) * ROWB;
   if (WK > 1) dyn = dyn < (size_t)4 * RT * 2 * 16 * 64 * 4 ? (size_t)4 * RT * 2 * 16 * 64 * 4 : dyn;
   if (dyn > 160 * 1024) return false;
-  auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB>;
+  auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB, T2>;
   static size_t limit = 0;
   if (dyn > limit) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(dyn < 65536 ? 65536 : dyn));
     limit = dyn < 65536 ? 65536 : dyn;
   }
-  const dim3 grid((unsigned)((k.M + R - 1) / R), (unsigned)((k.n_rt + WC * RT - 1) / (WC * RT)));
+  const dim3 grid((unsigned)blocks, (unsigned)((k.n_rt + WC * RT - 1) / (WC * RT)));
   hipLaunchKernelGGL(kernel, grid, dim3(256), dyn, st, k);
   return true;
+}
+
+// 16 x 16 tiles cover the map with at most ~6 % of the tile area outside it
+bool tiles_fit(int H, int W) {
+  const long covered = (long)((H + 15) / 16) * 16 * ((W + 15) / 16) * 16;
+  return covered * 100 <= (long)H * W * 106;
 }
 
 }  // namespace
@@ -309,27 +354,30 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
   k.out_scale = a->out_scale;
   hipStream_t st = (hipStream_t)stream;
   bool ok = false;
-  auto cfg = [&](int R, int WK) {
-    k.PR = R + 2 * a->W + 2;
+  const int B = a->B;
+  auto cfg = [&](int WK) {
     k.n_rounds = slices / WK;
     return slices % WK == 0;
   };
+  const bool big = (long)a->H * a->W >= 4096;     // (never a function of the batch size: WK changes the
+                                                  //  summation order, and a shard of a batch has to
+                                                  //  reproduce the full batch bit for bit)
+  const bool t2 = big && tiles_fit(a->H, a->W);
   if (a->N_pad == 32) {
-    // (the choice must not depend on the batch size: WK changes the summation order, and a shard of a
-    //  batch has to reproduce the full batch bit for bit)
-    if ((long)a->H * a->W >= 4096 && cfg(256, 1)) {
-      ok = try_launch<1, 4, 1, 1, 8, true, 2>(k, st) || try_launch<1, 4, 1, 1, 12, true, 1>(k, st);
+    if (big && cfg(1)) {
+      ok = (t2 && try_launch<1, 4, 1, 1, 6, true, 2, true>(k, B, st)) || try_launch<1, 4, 1, 1, 8, true, 2>(k, B, st) ||
+           try_launch<1, 4, 1, 1, 12, true, 1>(k, B, st);
     } else {
-      if (cfg(64, 4)) ok = try_launch<1, 1, 4, 1, 8, true, 2>(k, st) || try_launch<1, 1, 4, 1, 12, true, 2>(k, st);
-      if (!ok && cfg(128, 2)) ok = try_launch<1, 2, 2, 1, 12, true, 2>(k, st);
-      if (!ok && cfg(256, 1)) ok = try_launch<1, 4, 1, 1, 12, true, 1>(k, st);
+      if (cfg(4)) ok = try_launch<1, 1, 4, 1, 8, true, 2>(k, B, st) || try_launch<1, 1, 4, 1, 12, true, 2>(k, B, st);
+      if (!ok && cfg(2)) ok = try_launch<1, 2, 2, 1, 12, true, 2>(k, B, st);
+      if (!ok && cfg(1)) ok = try_launch<1, 4, 1, 1, 12, true, 1>(k, B, st);
     }
   } else if (a->N_pad == 64) {
-    if (cfg(256, 1)) ok = try_launch<1, 4, 1, 2, 6, true, 2>(k, st);
+    if (cfg(1)) ok = (t2 && try_launch<1, 4, 1, 2, 6, true, 2, true>(k, B, st)) || try_launch<1, 4, 1, 2, 6, true, 2>(k, B, st);
   } else if (a->N_pad == 128) {
-    if (cfg(128, 1)) ok = try_launch<2, 2, 1, 2, 6, true, 2>(k, st);
+    if (cfg(1)) ok = try_launch<2, 2, 1, 2, 6, true, 2>(k, B, st);
   } else {
-    if (cfg(64, 1)) ok = try_launch<4, 1, 1, 2, 4, true, 2>(k, st);
+    if (cfg(1)) ok = try_launch<4, 1, 1, 2, 4, true, 2>(k, B, st);
   }
   if (!ok) return cf_conv2d_f16x3(a, stream);
   return cf_check_launch("cf_conv3x3_f16x3");

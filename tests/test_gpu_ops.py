@@ -526,6 +526,9 @@ def test_conv2d_f16x3_fp32_level_accuracy(dev, B, Ci, Co, H, W, k, stride, act, 
     (1, 512, 512, 7, 13, 1, False, True),     # level5: two channel blocks
     (1, 64, 64, 5, 300, 1, False, True),      # too wide for the LDS patch: forwarded to the slot kernel
     (2, 16, 27, 1, 7, 0, False, True),        # single-row image (every dy != 0 tap is outside)
+    (1, 64, 64, 112, 200, 1, True, True),     # level2 at the bench size: 16x16 tiles of one image (2-D patch)
+    (2, 32, 27, 127, 127, 0, False, True),    # 2-D patch, last tile row / column one pixel short
+    (1, 64, 64, 127, 126, 1, False, True),
 ])
 def test_conv3x3_f16x3_patch(dev, B, Ci, Co, H, W, act, res, exact):
     """LDS-patch 3x3 kernel: fp32-level accuracy against float64, and - where the K loop is not split
