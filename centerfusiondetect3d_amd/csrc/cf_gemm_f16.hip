@@ -372,20 +372,20 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   store_b(smem, 0);
   if (p.n_chunks > 1) load_b(1);
   __syncthreads();
-  // straight-line body (look-ahead indices clamped, not branched); the sched_barriers keep the
-  // compiler from sinking the weight / corner prefetches down to their first use
-  const int last = p.n_chunks - 1;
+  // (no sched_barrier pinning here, unlike the conv kernels: with it the <2,2,1> instance produced
+  //  rare 4-pixel glitches when launched behind an unrelated kernel - tools/dbg_det2.py - while this
+  //  form is clean under the same stress)
   for (int c = 0; c < p.n_chunks; ++c) {
     unsigned char* cur = smem + (c & 1) * BUF;
     unsigned char* nxt = smem + ((c + 1) & 1) * BUF;
     mma_kstep(cur, 0, wh[0], wl[0]);
-    load_w(wh[0], wl[0], min(2 * c + 2, n_ks - 2));
-    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < p.n_chunks) load_w(wh[0], wl[0], 2 * c + 2);
     mma_kstep(cur, 1, wh[1], wl[1]);
-    load_w(wh[1], wl[1], min(2 * c + 3, n_ks - 1));
-    store_b(nxt, min(c + 1, last));        // (a repeat of the last chunk at the end: never read)
-    load_b(min(c + 2, last));
-    __builtin_amdgcn_sched_barrier(0);
+    if (c + 1 < p.n_chunks) {
+      load_w(wh[1], wl[1], 2 * c + 3);
+      store_b(nxt, c + 1);
+      if (c + 2 < p.n_chunks) load_b(c + 2);
+    }
     __syncthreads();
   }
 
