@@ -49,6 +49,14 @@ class HeadFusedArgs(C.Structure):
                 ("b_first", _f * CF_MAX_HEADS), ("layout3x3", C.c_int32), ("w_out_perm", _f * CF_MAX_HEADS)]
 
 
+class StemArgs(C.Structure):
+    _fields_ = [("x", _f), ("B", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("w_base", _f), ("b_base", _f), ("scale_base", C.c_float),
+                ("w_level0", _f), ("b_level0", _f), ("scale_level0", C.c_float),
+                ("w_level1", _f), ("b_level1", _f), ("scale_level1", C.c_float),
+                ("out", _f)]
+
+
 class DecodeArgs(C.Structure):
     _fields_ = [("scores", _f), ("inds", _f), ("classes", _f), ("reg", _f), ("wh", _f),
                 ("depth", _f), ("rot", _f), ("dim", _f), ("amodal", _f), ("att", _f), ("vel", _f),
@@ -63,6 +71,7 @@ SYMBOLS = {
     "cf_conv2d_bf16x3": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_conv2d_f16x3": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_conv3x3_f16x3": (_i, [C.POINTER(ConvArgs), _f]),
+    "cf_stem_fused": (_i, [C.POINTER(StemArgs), _f]),
     "cf_split_bf16": (_i, [_f, _f, C.c_long, _i, _i, _i, _f]),
     "cf_head_tail": (_i, [C.POINTER(HeadTailArgs), _f]),
     "cf_head_fused": (_i, [C.POINTER(HeadFusedArgs), _f]),
@@ -73,6 +82,7 @@ SYMBOLS = {
     "cf_nchw_to_nhwc4": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "cf_nhwc_to_nchw": (_i, [_f, _f, _i, _i, _i, _i, _i, _f]),
     "cf_topk_workspace_bytes": (C.c_size_t, [_i, _i]),
+    "cf_topk_workspace_bytes_nms": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "cf_topk_peaks": (_i, [_f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
     "cf_frustum_assoc": (_i, [_f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, C.c_float, _f, _f, _f, _f]),
     "cf_pillar_expand": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _i, _i, _d, _d, _d, _f, _f, _f, _f]),

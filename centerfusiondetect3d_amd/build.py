@@ -24,6 +24,7 @@ SOURCES = [
     ("cf_gemm_bf16.hip", []),
     ("cf_gemm_f16.hip", []),
     ("cf_conv3x3_f16.hip", []),
+    ("cf_stem.hip", []),
     ("cf_heads.hip", []),
     ("cf_elementwise.hip", []),
     ("cf_post.hip", ["-ffp-contract=off"]),

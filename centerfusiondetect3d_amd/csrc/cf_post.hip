@@ -19,8 +19,9 @@ constexpr int TOPK_CAP = 4096;      // candidate keys kept in LDS (32 KiB)
 constexpr int TOPK_SLICES = 16;     // workgroups per image in the slice pass
 constexpr int TOPK_MAXK = 256;      // K <= number of threads of the slice kernel
 
-__device__ __forceinline__ uint32_t f2u(float f) {  // order-preserving float -> uint
-  const uint32_t u = __float_as_uint(f);
+__device__ __forceinline__ uint32_t f2u(float f) {  // order-preserving float -> uint (-0 and +0 tie, as they compare)
+  uint32_t u = __float_as_uint(f);
+  u = (u == 0x80000000u) ? 0u : u;
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 __device__ __forceinline__ float u2f(uint32_t u) {
@@ -64,6 +65,17 @@ __device__ void bitonic_sort_desc(uint64_t* keys, int P) {
   }
 }
 
+// heat * (maxpool3x3(heat) == heat) as its own fully parallel pass (cf_topk_peaks, nms == 2): one
+// thread per element, rows of the 3x3 window served by L1/L2.
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ heat, float* __restrict__ out, int H,
+                                                  int W, long total) {
+  const long N = (long)H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long plane = i / N;
+    out[i] = peak_value<true>(heat + plane * N, (int)(i - plane * N), H, W);
+  }
+}
+
 // Pass 1: top-K of one SLICE of one image (TOPK_SLICES workgroups per image), as sorted 64-bit keys
 // (order-preserving score bits << 32 | ~flat_index), i.e. ordered by (score desc, flat index asc)
 // == (score desc, class asc, pixel asc).  Every element of the image's top-K is in its slice's
@@ -101,8 +113,14 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* _
   }
 
   // ---- A: lower bound from local maxima
+  // (NMS: the 3x3 neighbourhood is only looked at when the raw value could still matter - a
+  //  suppressed non-negative element becomes 0 <= raw, so raw <= bound settles it without the 9
+  //  loads; negative values, which suppression would RAISE to -0, always take the full path)
   uint32_t lmax = 0;
-  for (int i = lo + tid; i < hi; i += TOPK_THREADS) lmax = max(lmax, f2u(peak_value<NMS>(img, i, H, W)));
+  for (int i = lo + tid; i < hi; i += TOPK_THREADS) {
+    const float v = img[i];
+    if (!NMS || f2u(v) > lmax || v < 0.0f) lmax = max(lmax, f2u(peak_value<NMS>(img, i, H, W)));
+  }
   keys[tid] = lmax;
   __syncthreads();
   bitonic_sort_desc(keys, TOPK_THREADS);
@@ -114,7 +132,9 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* _
     if (tid == 0) s_gt = 0;
     __syncthreads();
     for (int i = lo + tid; i < hi; i += TOPK_THREADS) {
-      const uint32_t u = f2u(peak_value<NMS>(img, i, H, W));
+      const float v = img[i];
+      uint32_t u = f2u(v);
+      if (NMS && (u > L || v < 0.0f)) u = f2u(peak_value<NMS>(img, i, H, W));
       if (u > L) {
         const uint32_t pos = atomicAdd(&s_gt, 1u);
         if (pos < TOPK_CAP) keys[pos] = ((uint64_t)u << 32) | (uint32_t)(~(uint32_t)i);
@@ -159,7 +179,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* _
     int found = 0;
     for (int base = lo; base < hi && found < r; base += TOPK_THREADS) {
       const int i = base + tid;
-      const bool eq = (i < hi) && (f2u(peak_value<NMS>(img, i, H, W)) == L);
+      const bool eq = (i < hi) && (!NMS || f2u(img[i]) >= L || img[i] < 0.0f) && (f2u(peak_value<NMS>(img, i, H, W)) == L);
       const unsigned long long bal = __ballot(eq);
       if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
       __syncthreads();
@@ -619,6 +639,11 @@ extern "C" size_t cf_topk_workspace_bytes(int B, int K) {
   return (size_t)(B > 0 ? B : 0) * TOPK_SLICES * (size_t)(K > 0 ? K : 0) * sizeof(uint64_t);
 }
 
+extern "C" size_t cf_topk_workspace_bytes_nms(int B, int C, int H, int W, int K) {
+  const size_t map = (size_t)(B > 0 ? B : 0) * (size_t)(C > 0 ? C : 0) * (size_t)(H > 0 ? H : 0) * (size_t)(W > 0 ? W : 0);
+  return ((cf_topk_workspace_bytes(B, K) + 255) / 256) * 256 + map * sizeof(float);
+}
+
 extern "C" int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
                              int32_t* inds, int32_t* classes, void* workspace, void* stream) {
   CF_REQUIRE(heat && scores && inds && classes && workspace, "cf_topk_peaks: null buffer");
@@ -628,6 +653,15 @@ extern "C" int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int 
   CF_REQUIRE((long)C * H * W < (1L << 31), "cf_topk_peaks: image too large");
   hipStream_t st = (hipStream_t)stream;
   uint64_t* keys = static_cast<uint64_t*>(workspace);
+  CF_REQUIRE(nms >= 0 && nms <= 2, "cf_topk_peaks: nms=%d", nms);
+  if (nms == 2) {   // suppressed map first (scratch behind the keys), then the plain top-K over it
+    float* sup = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + ((cf_topk_workspace_bytes(B, K) + 255) / 256) * 256);
+    const long total = (long)B * C * H * W;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(nms_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, heat, sup, H, W, total);
+    heat = sup;
+    nms = 0;
+  }
   if (nms)
     hipLaunchKernelGGL(topk_slice_kernel<true>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys);
   else

@@ -256,18 +256,27 @@ class _Plan:
                 layers[i] = dcn_node(f"{p}.node_{j}", summed)
 
         # ---- backbone
-        self.x4 = buf(B, H, W, 4)
         self.in_step = len(self.steps)
-        self.steps.append(None)                            # nchw_to_nhwc4(images): patched per call
-        t, _ = conv("base.base_layer", [self.x4], H, W)
-        y0, _ = conv("base.level0", [t], H, W)
-        y1, _ = conv("base.level1", [y0], H, W)
+        self.steps.append(None)                            # first step reads the images: patched per call
+        self.stem = None
+        if "base.stem" in pk:
+            # base_layer + level0 + level1 in one launch; the full-resolution maps stay in LDS
+            y0, y1 = None, buf(B, H // 2, W // 2, 32)
+            self.stem = ops.stem_args(pk["base.stem"], None, y1, shape=(B, 3, H, W))
+            self.keep.append(self.stem)
+            self.step_index["base.stem"] = self.in_step
+            self.step_flops["base.stem"] = 2.0 * B * H * W * (16 * 147 + 16 * 144 + 32 * 144 / 4)
+        else:
+            self.x4 = buf(B, H, W, 4)
+            t, _ = conv("base.base_layer", [self.x4], H, W)
+            y0, _ = conv("base.level0", [t], H, W)
+            y1, _ = conv("base.level1", [y0], H, W)
         layers = [y0, y1]
         x = y1
         for lvl, levels, root in ((2, 1, False), (3, 2, True), (4, 2, True), (5, 1, True)):
             x = tree(f"base.level{lvl}", levels, x, 2, root)
             layers.append(x)
-        self.debug = {f"y{i}": t for i, t in enumerate(layers)}   # NHWC stage outputs (tests only)
+        self.debug = {f"y{i}": t for i, t in enumerate(layers) if t is not None}   # NHWC stage outputs (tests only)
         # ---- DLA-up + IDA-up neck
         out = [layers[-1]]
         for i in range(len(layers) - 2 - 1):
@@ -415,7 +424,11 @@ class _Plan:
         y["depth"] = new(1)
         set_out("depth", y["depth"], second=True)
         y["calib"] = calib
-        self.steps[self.in_step] = (lib.cf_nchw_to_nhwc4, x.data_ptr(), self.x4.data_ptr(), B, 3, H, W)
+        if self.stem is not None:
+            self.stem.x = x.data_ptr()
+            self.steps[self.in_step] = (lib.cf_stem_fused, C.byref(self.stem))
+        else:
+            self.steps[self.in_step] = (lib.cf_nchw_to_nhwc4, x.data_ptr(), self.x4.data_ptr(), B, 3, H, W)
         if self.radar:
             pc_hm = new(3)
             self.steps[self.topk_step] = (lib.cf_topk_peaks, y["heatmap"].data_ptr(), B, heads["heatmap"],
@@ -490,6 +503,7 @@ class DLASeg(nn.Module):
         self._plans = {}
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
+        self.stem_fused = True   # with conv_f16: base_layer + level0 + level1 in one launch (cf_stem.hip)
         self.conv_patch = True   # 3x3 stride-1 f16x3 convs: LDS patch reuse (cf_conv3x3_f16.hip)
         self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)
         self.heads_fused = True  # with heads_bf16: one launch per head group, hidden maps stay in LDS
@@ -529,9 +543,14 @@ class DLASeg(nn.Module):
             w, b = packing.fold_bn(sd[wkey], bias, bn(bnkey) if bnkey else None)
             pk[name] = pack_any(w, b, sources, stride=stride)
 
-        conv_bn("base.base_layer", "base.base_layer.0.weight", "base.base_layer.1", [Source(3, 4)])
-        conv_bn("base.level0", "base.level0.0.weight", "base.level0.1", [Source(16, 16)])
-        conv_bn("base.level1", "base.level1.0.weight", "base.level1.1", [Source(16, 16)], stride=2)
+        if f16 and self.stem_fused:
+            folded = [packing.fold_bn(sd[f"base.{n}.0.weight"], None, bn(f"base.{n}.1"))
+                      for n in ("base_layer", "level0", "level1")]
+            pk["base.stem"] = packing.pack_stem(*[t for wb in folded for t in wb]).to(device)
+        else:
+            conv_bn("base.base_layer", "base.base_layer.0.weight", "base.base_layer.1", [Source(3, 4)])
+            conv_bn("base.level0", "base.level0.0.weight", "base.level0.1", [Source(16, 16)])
+            conv_bn("base.level1", "base.level1.0.weight", "base.level1.1", [Source(16, 16)], stride=2)
 
         def tree1(p, ci, co, root_srcs):
             conv_bn(p + ".tree1.conv1", p + ".tree1.conv1.weight", p + ".tree1.bn1", [Source(ci, ci)],

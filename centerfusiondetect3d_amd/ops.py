@@ -240,7 +240,8 @@ def nhwc_to_nchw(x, channels=None, out=None):
 
 
 def topk_peaks(heat, K=100, nms=False):
-    """(B,C,H,W) NCHW scores -> scores (B,K) f32, inds (B,K) i32, classes (B,K) i32."""
+    """(B,C,H,W) NCHW scores -> scores (B,K) f32, inds (B,K) i32, classes (B,K) i32.
+    nms: False / True (3x3 equality NMS first; True = the two-pass form, 1 = suppress on the fly)."""
     _need_cuda(heat)
     if not heat.is_contiguous():
         heat = heat.contiguous()
@@ -250,8 +251,10 @@ def topk_peaks(heat, K=100, nms=False):
     inds = torch.empty((B, K), device=dev, dtype=torch.int32)
     classes = torch.empty((B, K), device=dev, dtype=torch.int32)
     lib = _lib.load()
-    ws = torch.empty(max(1, lib.cf_topk_workspace_bytes(B, K)), device=dev, dtype=torch.uint8)
-    _lib.check(lib.cf_topk_peaks(heat.data_ptr(), B, Cc, H, W, K, int(bool(nms)),
+    mode = int(nms) if nms in (0, 1, 2) and not isinstance(nms, bool) else (2 if nms else 0)
+    size = lib.cf_topk_workspace_bytes_nms(B, Cc, H, W, K) if mode == 2 else lib.cf_topk_workspace_bytes(B, K)
+    ws = torch.empty(max(1, size), device=dev, dtype=torch.uint8)
+    _lib.check(lib.cf_topk_peaks(heat.data_ptr(), B, Cc, H, W, K, mode,
                                  scores.data_ptr(), inds.data_ptr(), classes.data_ptr(),
                                  ws.data_ptr(), _lib.stream_ptr()), "cf_topk_peaks")
     return scores, inds, classes
@@ -319,3 +322,26 @@ def pillar_expand(pc_2d, pc_3d, counts, calib, trans, out_hw, pillar_dims=(1.5, 
                                             pc_dep.data_ptr(), _lib.ptr(keep), _lib.ptr(xy),
                                             _lib.stream_ptr()), "cf_pillar_expand")
     return (pc_dep, keep, xy) if want_aux else pc_dep
+
+
+def stem_args(ps, x, out, shape=None) -> _lib.StemArgs:
+    """x may be None with shape=(B, C, H, W) given: the image pointer is then patched in per call."""
+    a = _lib.StemArgs()
+    B, Cc, H, W = shape if x is None else x.shape
+    a.x, a.B, a.C, a.H, a.W = (_lib.ptr(x), B, Cc, H, W)
+    a.w_base, a.b_base, a.scale_base = ps.w_base.data_ptr(), ps.b_base.data_ptr(), ps.scale_base
+    a.w_level0, a.b_level0, a.scale_level0 = ps.w_level0.data_ptr(), ps.b_level0.data_ptr(), ps.scale_level0
+    a.w_level1, a.b_level1, a.scale_level1 = ps.w_level1.data_ptr(), ps.b_level1.data_ptr(), ps.scale_level1
+    a.out = out.data_ptr()
+    return a
+
+
+def stem_fused(ps, x, out=None):
+    """images (B, C<=3, H, W) fp32 NCHW -> level1 map (B, H/2, W/2, 32) fp32 NHWC (packing.pack_stem)."""
+    _need_cuda(x)
+    B, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, H // 2, W // 2, 32), device=x.device, dtype=torch.float32)
+    a = stem_args(ps, x.contiguous(), out)
+    _lib.check(_lib.load().cf_stem_fused(C.byref(a), _lib.stream_ptr()), "cf_stem_fused")
+    return out

@@ -276,3 +276,78 @@ def pack_dcn_f16(weight, bias) -> PackedDcn:
 def pack_upsample(weight):
     """ConvTranspose2d depthwise weight (C,1,k,k) -> [k][k][C]."""
     return weight.detach().float().cpu()[:, 0].permute(1, 2, 0).contiguous()
+
+
+def _f16_split(w):
+    """fp64/fp32 tensor -> (2^s * w) split into fp16 hi / lo, and the exponent s (max|w| -> [2^13, 2^14))."""
+    wmax = float(w.abs().max())
+    s_exp = int(torch.floor(torch.log2(torch.tensor(16384.0 / wmax)))) if wmax > 0 else 0
+    ws = (w.double() * 2.0 ** s_exp).float()
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+    return hi, lo, s_exp
+
+
+@dataclass
+class PackedStem:
+    w_base: torch.Tensor
+    b_base: torch.Tensor
+    w_level0: torch.Tensor
+    b_level0: torch.Tensor
+    w_level1: torch.Tensor
+    b_level1: torch.Tensor
+    scale_base: float
+    scale_level0: float
+    scale_level1: float
+
+    def to(self, device):
+        for k in ("w_base", "b_base", "w_level0", "b_level0", "w_level1", "b_level1"):
+            setattr(self, k, getattr(self, k).to(device).contiguous())
+        return self
+
+
+def pack_stem(w_base, b_base, w_l0, b_l0, w_l1, b_l1) -> PackedStem:
+    """Weights of cf_stem_fused (BN already folded) in v_mfma_f32_16x16x32_f16 A-operand order: lane
+    l = 16 kg + row holds the 8 k-values of k group kg.
+      base_layer (16, C<=3, 7, 7): 13 k-steps of 4 taps (49 + 3 padding); a k group = ONE tap with
+        k = [4 channels | the same 4 channels] - variant 0 holds {w_hi, w_hi}, variant 1 {w_lo, 0}, to meet
+        the activations stored as [4 ch hi | 4 ch lo];
+      level0 (16, 16, 3, 3) / level1 (32, 16, 3, 3): 5 k-steps of 2 taps (9 + 1 padding); k group kg =
+        channels 8 (kg & 1) .. +8 of tap 2 ks + (kg >> 1); planes hi, lo; level1 has two 16-row tiles."""
+    assert w_base.shape[0] == 16 and w_base.shape[1] <= 3 and tuple(w_base.shape[2:]) == (7, 7)
+    assert tuple(w_l0.shape) == (16, 16, 3, 3) and tuple(w_l1.shape) == (32, 16, 3, 3)
+    hi, lo, s0 = _f16_split(w_base)
+    cb = w_base.shape[1]
+    fb = torch.zeros(13, 2, 64, 8, dtype=torch.float16)
+    for ks in range(13):
+        for kg in range(4):
+            tap = 4 * ks + kg
+            if tap >= 49:
+                continue
+            ky, kx = divmod(tap, 7)
+            rows = slice(16 * kg, 16 * kg + 16)
+            fb[ks, 0, rows, 0:cb] = hi[:, :, ky, kx]
+            fb[ks, 0, rows, 4:4 + cb] = hi[:, :, ky, kx]
+            fb[ks, 1, rows, 0:cb] = lo[:, :, ky, kx]
+
+    def frag3(w):
+        h, l, s = _f16_split(w)
+        n_rt = w.shape[0] // 16
+        f = torch.zeros(n_rt, 5, 2, 64, 8, dtype=torch.float16)
+        for rt in range(n_rt):
+            for ks in range(5):
+                for kg in range(4):
+                    tap = 2 * ks + (kg >> 1)
+                    if tap >= 9:
+                        continue
+                    ky, kx = divmod(tap, 3)
+                    ch = slice(8 * (kg & 1), 8 * (kg & 1) + 8)
+                    rows = slice(16 * kg, 16 * kg + 16)
+                    f[rt, ks, 0, rows] = h[16 * rt:16 * rt + 16, ch, ky, kx]
+                    f[rt, ks, 1, rows] = l[16 * rt:16 * rt + 16, ch, ky, kx]
+        return f, s
+
+    f0, s1 = frag3(w_l0)
+    f1, s2 = frag3(w_l1)
+    return PackedStem(fb, b_base.float().clone(), f0[0].contiguous(), b_l0.float().clone(), f1, b_l1.float().clone(),
+                      2.0 ** -(s0 + 4), 2.0 ** -(s1 + 4), 2.0 ** -(s2 + 4))

@@ -81,6 +81,22 @@ typedef struct cf_conv_args {
 } cf_conv_args;
 int cf_conv2d_fused(const cf_conv_args* a, void* stream);
 
+/* cf_stem_fused: the DLA-34 stem in one launch - base_layer 7x7 (C -> 16), level0 3x3 (16 -> 16) and
+ * level1 3x3 stride 2 (16 -> 32), each followed by its folded BatchNorm and ReLU
+ * (model/networks/dla.py:237-262: DLA.base_layer, level0, level1) - straight from the NCHW image batch
+ * to the half-resolution fp32 NHWC level1 map; the full-resolution intermediates stay in LDS
+ * (cf_stem.hip).  f16x3 arithmetic (fp32-level accuracy).  Weights: MFMA 16x16x32 fragment order as
+ * produced by packing.pack_stem; scale_* = 2^-(s+4) of the layer. */
+typedef struct cf_stem_args {
+  const float* x;                 /* images, fp32 NCHW (B, C, H, W), C <= 3                    */
+  int32_t B, C, H, W;             /* H, W even                                                 */
+  const void* w_base;   const float* b_base;   float scale_base;
+  const void* w_level0; const float* b_level0; float scale_level0;
+  const void* w_level1; const float* b_level1; float scale_level1;
+  float* out;                     /* fp32 NHWC (B, H/2, W/2, 32)                               */
+} cf_stem_args;
+int cf_stem_fused(const cf_stem_args* a, void* stream);
+
 /* cf_conv2d_bf16x3: the same implicit GEMM on the bf16 MFMA pipe with split operands
  * (x = hi + lo, both bf16; a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate; <= ~2^-17
  * relative error per product at 5.3x the fp32-MFMA rate).  Used for the head convolutions
@@ -212,6 +228,10 @@ int cf_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, int C, int 
  * outputs: scores (B,K) f32, inds (B,K) i32 pixel index in [0,H*W), classes (B,K) i32.
  * workspace: cf_topk_workspace_bytes(B, K) bytes of device memory (per-slice candidate keys). */
 size_t cf_topk_workspace_bytes(int B, int K);
+/* nms == 2: the same result as nms == 1, but the suppressed map is first written by its own fully
+ * parallel pass into scratch memory behind the keys - workspace must then hold
+ * cf_topk_workspace_bytes_nms(B, C, H, W, K) bytes.  (nms == 1 suppresses on the fly, no scratch.) */
+size_t cf_topk_workspace_bytes_nms(int B, int C, int H, int W, int K);
 int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
                   int32_t* inds, int32_t* classes, void* workspace, void* stream);
 

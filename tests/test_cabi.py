@@ -29,6 +29,7 @@ def test_header_symbols_all_exported_and_bound():
     assert set(_lib.SYMBOLS) == set(names)
     assert lib.cf_abi_version() == 1
     assert lib.cf_topk_workspace_bytes(16, 100) == 16 * 16 * 100 * 8
+    assert lib.cf_topk_workspace_bytes_nms(16, 10, 112, 200, 100) == 16 * 16 * 100 * 8 + 16 * 10 * 112 * 200 * 4
 
 
 def test_struct_layouts_match_c(tmp_path):

@@ -177,13 +177,19 @@ def _check_topk(dev, heat, K, nms):
     from centerfusiondetect3d_amd import ops
     ref_heat = decode_ref.nms(heat) if nms else heat
     s, inds, cls, _, _ = frustum_ref.topk(ref_heat, K)
+    if nms:      # negative scores: suppression RAISES them to -0 (heat * keep), both device forms must agree
+        neg = (heat - 0.5).to(dev)
+        a, b = ops.topk_peaks(neg, K, nms=True), ops.topk_peaks(neg, K, nms=1)
+        r = frustum_ref.topk(decode_ref.nms(heat - 0.5), K)
+        for x, y, z in zip(a, b, r[:3]):
+            assert torch.equal(x, y) and np.array_equal(x.cpu().numpy(), z.numpy())
     gs, gi, gc = ops.topk_peaks(heat.to(dev), K, nms=nms)
     assert np.array_equal(gs.cpu().numpy(), s.numpy())
     assert np.array_equal(gi.cpu().numpy(), inds.numpy())
     assert np.array_equal(gc.cpu().numpy(), cls.numpy())
 
 
-@pytest.mark.parametrize("nms", [False, True])
+@pytest.mark.parametrize("nms", [False, True, 1])     # True: suppressed map first (two passes); 1: on the fly
 def test_topk_random_and_ties(dev, nms):
     _check_topk(dev, cases.decode_case(0)["heatmap"], 100, nms)              # tie-free
     _check_topk(dev, cases.decode_case(3, tie_heavy=True)["heatmap"], 100, nms)  # plateau + ties
@@ -590,3 +596,27 @@ def test_dcn_v2_f16x3(dev, B, Ci, Co, H, W, mag):
     err = float((nchw(out).cpu().double() - ref).abs().max() / ref.abs().max())
     print(f"[dcn f16x3] C={Ci}->{Co}: max|err|/max|ref| = {err:.2e}")
     assert err < 5e-6, err
+
+
+# ----------------------------------------------------------------------------------- fused stem
+@pytest.mark.parametrize("B,C,H,W", [(2, 3, 64, 96), (1, 3, 16, 16), (1, 3, 34, 50), (3, 1, 18, 130), (1, 3, 160, 224)])
+def test_stem_fused(dev, B, C, H, W):
+    """base_layer 7x7 + level0 3x3 + level1 3x3/2 (+ bias + ReLU each) in one launch against float64
+    torch: per-layer zero padding at the image border, ragged level1 tiles, fp32-level accuracy."""
+    from centerfusiondetect3d_amd import ops, packing
+    x = rnd(B, C, H, W, seed=1) * 2
+    wb, bb = rnd(16, C, 7, 7, seed=2, scale=(C * 49) ** -0.5), rnd(16, seed=3, scale=0.3)
+    w0, b0 = rnd(16, 16, 3, 3, seed=4, scale=144 ** -0.5), rnd(16, seed=5, scale=0.3)
+    w1, b1 = rnd(32, 16, 3, 3, seed=6, scale=144 ** -0.5), rnd(32, seed=7, scale=0.3)
+    t = F.relu(F.conv2d(x.double(), wb.double(), bb.double(), 1, 3))
+    t = F.relu(F.conv2d(t, w0.double(), b0.double(), 1, 1))
+    ref = F.relu(F.conv2d(t, w1.double(), b1.double(), 2, 1))
+    ps = packing.pack_stem(wb, bb, w0, b0, w1, b1).to(dev)
+    out = ops.stem_fused(ps, x.to(dev))
+    assert out.shape == (B, H // 2, W // 2, 32)
+    got = nchw(out).cpu().double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    t32 = F.relu(F.conv2d(F.relu(F.conv2d(F.relu(F.conv2d(x, wb, bb, 1, 3)), w0, b0, 1, 1)), w1, b1, 2, 1))
+    err32 = float((t32.double() - ref).abs().max() / ref.abs().max())
+    print(f"[stem] {B}x{C}x{H}x{W}: max|err|/max|ref| = {err:.2e} (torch fp32 chain: {err32:.2e})")
+    assert err < 2e-6, err

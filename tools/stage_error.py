@@ -36,5 +36,6 @@ dbg = dict(plan.debug); dbg["feat"]=plan.feat
 def nerr(a,b): return float((a-b).abs().max()/b.abs().max())
 def rerr(a,b): return float((a-b).pow(2).mean().sqrt()/b.pow(2).mean().sqrt())
 for k in r64:
+    if k not in dbg: continue   # (y0 stays in LDS when the stem is fused)
     g = dbg[k].permute(0,3,1,2).double().cpu()
     print(f"{k:>5s}: max-norm gpu-vs-fp64 {nerr(g,r64[k]):.2e} cpu32-vs-fp64 {nerr(r32[k].double(),r64[k]):.2e} | rms gpu-vs-fp64 {rerr(g,r64[k]):.2e} cpu32-vs-fp64 {rerr(r32[k].double(),r64[k]):.2e}")
