@@ -12,9 +12,9 @@ configs[1]: Centerfusion_Middle, bs=16 per GPU, 3x448x800, <=200-point synthetic
 random-init weights (no network for checkpoints).  Weak scaling: every rank runs its own 16 frames.
 
 Prints ONE JSON line on rank 0 (see the task contract); `roofline` is the dominant kernel
-(head_fused_kernel: the 7 primary and the 4 secondary heads, 3x3 conv + 1x1 chain each in one launch,
-58 % of all FLOPs) timed with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a
-port, not the reference) timed on this host on a bounded sample.
+(head_patch_kernel: the 7 primary and the 4 secondary heads, 3x3 conv + 1x1 chain each in one launch,
+58 % of all FLOPs, a third of the step) timed with HIP events on the launch stream; `cpu_baseline` is
+the CPU oracle (a port, not the reference) timed on this host on a bounded sample.
 """
 import argparse
 import json
@@ -32,18 +32,20 @@ METRIC = "frames/sec/GPU CenterFusion forward, 3x448x800 bs=16; 1/2/4/8-GPU scal
 GFLOP_PER_FRAME = 167.49          # 2 x 83.74 GMAC (conv + DCN + offset conv + convT)
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16 (v_mfma_f32_32x32x16_bf16)
-# dominant kernel = head_fused_kernel: its two launches per step (7 primary heads; 4 secondary heads)
+# dominant kernel = head_patch_kernel (cf_head_fused): its two launches per step (7 primary heads; 4 secondary heads)
 DOMINANT = ["tails.primary", "tails.secondary"]
 # HBM-side bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes over this same command (FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md §HBM); bench.py cannot
 # run the profiler on itself, so the committed measurement is reported.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_c_pmc_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_e_pmc_hbm_traffic.json")
 
 
-def measured_traffic(kernel="head_fused_kernel"):
+def measured_traffic(kernels=("head_patch_kernel<4, false>", "head_patch_kernel<4, true>")):
+    """Average HBM-side bytes per launch over the dominant kernel's two instantiations."""
     try:
-        d = json.load(open(TRAFFIC_FILE))[kernel]
-        return round(d["fetch_bytes_per_launch_x2_corrected"] + d["write_bytes_per_launch"])
+        t = json.load(open(TRAFFIC_FILE))
+        per = [t[k]["fetch_bytes_per_launch_x2_corrected"] + t[k]["write_bytes_per_launch"] for k in kernels]
+        return round(sum(per) / len(per))
     except Exception:
         return None
 
@@ -235,7 +237,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
                          "traffic": measured_traffic(),
-                         "kernel": "head_fused_kernel (2 launches/step: 7 primary heads, 4 secondary heads)",
+                         "kernel": "head_patch_kernel (cf_head_fused; 2 launches/step: 7 primary heads, 4 secondary heads)",
                          "note": "algorithmic FLOPs (2*MACs); the kernel issues 3 bf16 MFMA passes per MAC "
                                  "(split operands), so MFMA-pipe utilisation is 3x frac",
                          "flop_per_launch": launch_flops, "avg_launch_ms": round(avg_ms, 4),

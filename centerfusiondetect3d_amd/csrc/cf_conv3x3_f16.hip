@@ -51,11 +51,14 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int wk = wave % WK, wp = (wave / WK) % WP, wc = wave / (WK * WP);
-  int m0 = blockIdx.x * R;                  // flat: first pixel; T2: first pixel of the image + tile origin below
+  // consecutive tiles on ONE XCD (cf_xcd_remap): neighbouring patches overlap, and every round
+  // re-touches the same rows - both should hit that XCD's L2
+  const int bid = cf_xcd_remap(blockIdx.x, gridDim.x);
+  int m0 = bid * R;                         // flat: first pixel; T2: first pixel of the image + tile origin below
   int ty0 = 0, tx0 = 0;
   if (T2) {
     const int per_img = p.tiles_x * p.tiles_y;
-    const int b = blockIdx.x / per_img, rem = blockIdx.x - b * per_img;
+    const int b = bid / per_img, rem = bid - b * per_img;
     ty0 = (rem / p.tiles_x) * (R / 16);
     tx0 = (rem % p.tiles_x) * 16;
     m0 = b * p.HW;

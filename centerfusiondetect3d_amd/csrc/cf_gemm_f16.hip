@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvF p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int wc = wave / WP, wp = wave % WP;
-  const int m0 = blockIdx.x * PXB;
+  const int m0 = cf_xcd_remap(blockIdx.x, gridDim.x) * PXB;   // consecutive pixel tiles share an XCD (L2)
   const int rt0 = (blockIdx.y * WC + wc) * RT;          // first 32-row tile of this wave
   const bool w_ok = rt0 < p.n_rt;                       // (RT divides the padded tile count)
   const int n_ks = p.n_chunks * 2;
@@ -235,13 +235,21 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   constexpr int PXB = 64 * WP;
   constexpr int PLANE = PXB * FROWB;
   constexpr int BUF = 2 * PLANE;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + PXB * 9 * 16];
-  f32x4* desc = reinterpret_cast<f32x4*>(smem + 2 * BUF);   // {h, w, 16*sigmoid(mask), -} per (pixel, tap)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + PXB * 9 * 32];
+  // sampling descriptor of one (pixel, tap), built ONCE per tile:
+  //   dA = {element offset of the top-left corner (clamped into the image), step to the right corner
+  //         (0 or C), step to the bottom corner (0 or W*C), 16 * sigmoid(mask)}
+  //   dB = the four bilinear weights, ZERO where the corner lies outside the image
+  // so the per-chunk staging is 8 unconditional loads (every address valid), 4 multiply-adds per
+  // channel and the split - no floor / compare / branch in the K loop.
+  f32x4* desc = reinterpret_cast<f32x4*>(smem + 2 * BUF);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int wc = wave / WP, wp = wave % WP;
-  const int m0 = blockIdx.x * PXB;
+  // consecutive pixel tiles on ONE XCD: the gathered rows of a tile and of its neighbours then meet
+  // in that XCD's L2 instead of being fetched by all eight (hardware deals workgroups round-robin)
+  const int m0 = cf_xcd_remap(blockIdx.x, gridDim.x) * PXB;
   const int rt0 = (blockIdx.y * WC + wc) * RT;
   const bool w_ok = rt0 < p.n_rt;
   const int n_ks = p.n_chunks * 2;
@@ -250,65 +258,69 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   for (int i = tid; i < PXB * 9; i += 256) {
     const int r = i / 9, tap = i - r * 9;
     const int m = m0 + r;
-    f32x4 d = {-1.0e9f, -1.0e9f, 0.0f, 0.0f};
+    f32x4 dA = {0.0f, 0.0f, 0.0f, 0.0f}, dB = {0.0f, 0.0f, 0.0f, 0.0f};
     if (m < p.M) {
       const int b = m / HW, rem = m - b * HW;
       const int ho = rem / p.W, wo = rem - ho * p.W;
       const float* om = p.om + (size_t)m * p.om_stride;
       const int ti = tap / 3, tj = tap - ti * 3;
-      d[0] = (float)(ho - 1 + ti) + om[2 * tap];
-      d[1] = (float)(wo - 1 + tj) + om[2 * tap + 1];
-      d[2] = cf_sigmoid(om[18 + tap]) * ASCALE;
+      const float hf = (float)(ho - 1 + ti) + om[2 * tap];
+      const float wf = (float)(wo - 1 + tj) + om[2 * tap + 1];
+      const bool inside = hf > -1.0f && hf < (float)p.H && wf > -1.0f && wf < (float)p.W;
+      const float hfl = floorf(hf), wfl = floorf(wf);
+      const int hl = inside ? (int)hfl : 0, wl = inside ? (int)wfl : 0;
+      const float lh = hf - hfl, lw = wf - wfl, hh = 1.0f - lh, hw = 1.0f - lw;
+      const bool t_ok = inside && hl >= 0, b_ok = inside && hl + 1 <= p.H - 1;
+      const bool l_ok = wl >= 0, r_ok = wl + 1 <= p.W - 1;
+      const int y0 = max(hl, 0), x0 = max(wl, 0);
+      const int y1 = min(hl + 1, p.H - 1), x1 = min(wl + 1, p.W - 1);     // (hl + 1 >= 0 whenever inside)
+      dA[0] = __int_as_float(((b * p.H + y0) * p.W + x0) * p.C);
+      dA[1] = __int_as_float((max(x1, x0) - x0) * p.C);
+      dA[2] = __int_as_float((max(y1, y0) - y0) * p.W * p.C);
+      dA[3] = cf_sigmoid(om[18 + tap]) * ASCALE;
+      dB[0] = (t_ok && l_ok) ? hh * hw : 0.0f;
+      dB[1] = (t_ok && r_ok) ? hh * lw : 0.0f;
+      dB[2] = (b_ok && l_ok) ? lh * hw : 0.0f;
+      dB[3] = (b_ok && r_ok) ? lh * lw : 0.0f;
+      // a corner that is clamped away shares its address with a valid one, so its weight must be zero:
+      // true by construction (x1 == x0 only if !l_ok or !r_ok; y1 == y0 only if !t_ok or !b_ok)
     }
-    desc[i] = d;
-  }
-  int boff[WP];
-#pragma unroll
-  for (int i = 0; i < WP; ++i) {
-    const int m = m0 + ((tid + 256 * i) >> 2);
-    boff[i] = (m < p.M ? m / HW : 0) * HW;
+    desc[2 * i] = dA;
+    desc[2 * i + 1] = dB;
   }
   __syncthreads();
 
   f32x4 cv[WP][4][2];   // 4 corners x 8 channels, requested one chunk ahead
-  f32x4 cw[WP];         // corner weights (mask and activation scale folded in)
+  f32x4 cw[WP];         // corner weights
+  float cmk[WP];        // 16 * sigmoid(mask)
   auto load_b = [&](int c) {
     const int tap = c / p.chunks_per_tap;
     const int c0 = (c - tap * p.chunks_per_tap) * 32 + (tid & 3) * 8;
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
-      const f32x4 d = desc[((tid + 256 * i) >> 2) * 9 + tap];
-      const float hf = d[0], wf = d[1];
-      const bool inside = hf > -1.0f && hf < (float)p.H && wf > -1.0f && wf < (float)p.W;
-      const float hfl = floorf(hf), wfl = floorf(wf);
-      const int hl = (int)hfl, wl = (int)wfl;
-      const float lh = hf - hfl, lw = wf - wfl, hh = 1.0f - lh, hw = 1.0f - lw;
-      const bool t_ok = inside && hl >= 0, b_ok = inside && hl + 1 <= p.H - 1;
-      const bool l_ok = wl >= 0, r_ok = wl + 1 <= p.W - 1;
-      const float* base = p.x + (size_t)boff[i] * p.C + c0;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const float* a0 = base + (size_t)(hl * p.W + wl) * p.C;
-      const float* a1 = a0 + p.C;
-      const float* a2 = a0 + (size_t)p.W * p.C;
-      const float* a3 = a2 + p.C;
-      cv[i][0][0] = (t_ok && l_ok) ? *reinterpret_cast<const f32x4*>(a0) : z;
-      cv[i][0][1] = (t_ok && l_ok) ? *reinterpret_cast<const f32x4*>(a0 + 4) : z;
-      cv[i][1][0] = (t_ok && r_ok) ? *reinterpret_cast<const f32x4*>(a1) : z;
-      cv[i][1][1] = (t_ok && r_ok) ? *reinterpret_cast<const f32x4*>(a1 + 4) : z;
-      cv[i][2][0] = (b_ok && l_ok) ? *reinterpret_cast<const f32x4*>(a2) : z;
-      cv[i][2][1] = (b_ok && l_ok) ? *reinterpret_cast<const f32x4*>(a2 + 4) : z;
-      cv[i][3][0] = (b_ok && r_ok) ? *reinterpret_cast<const f32x4*>(a3) : z;
-      cv[i][3][1] = (b_ok && r_ok) ? *reinterpret_cast<const f32x4*>(a3 + 4) : z;
-      const f32x4 w = {hh * hw, hh * lw, lh * hw, lh * lw};
-      cw[i] = w;   // the mask (x 2^4 activation scale) is applied after the 4-corner sum, as the reference does
+      const int e = (((tid + 256 * i) >> 2) * 9 + tap) * 2;
+      const f32x4 dA = desc[e];
+      cw[i] = desc[e + 1];
+      cmk[i] = dA[3];
+      const float* a0 = p.x + (__float_as_int(dA[0]) + c0);
+      const float* a1 = a0 + __float_as_int(dA[1]);
+      const float* a2 = a0 + __float_as_int(dA[2]);
+      const float* a3 = a2 + __float_as_int(dA[1]);
+      cv[i][0][0] = *reinterpret_cast<const f32x4*>(a0);
+      cv[i][0][1] = *reinterpret_cast<const f32x4*>(a0 + 4);
+      cv[i][1][0] = *reinterpret_cast<const f32x4*>(a1);
+      cv[i][1][1] = *reinterpret_cast<const f32x4*>(a1 + 4);
+      cv[i][2][0] = *reinterpret_cast<const f32x4*>(a2);
+      cv[i][2][1] = *reinterpret_cast<const f32x4*>(a2 + 4);
+      cv[i][3][0] = *reinterpret_cast<const f32x4*>(a3);
+      cv[i][3][1] = *reinterpret_cast<const f32x4*>(a3 + 4);
     }
   };
-  auto store_b = [&](unsigned char* buf, int c) {
-    const int tap = c / p.chunks_per_tap;
+  auto store_b = [&](unsigned char* buf) {
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
       const int pr = tid + 256 * i;
-      const float mk = desc[(pr >> 2) * 9 + tap][2];
+      const float mk = cmk[i];   // the mask (x 2^4 activation scale) is applied after the 4-corner sum, as the reference does
       f32x4 v0 = (cw[i][0] * cv[i][0][0] + cw[i][1] * cv[i][1][0] + cw[i][2] * cv[i][2][0] + cw[i][3] * cv[i][3][0]) * mk;
       f32x4 v1 = (cw[i][0] * cv[i][0][1] + cw[i][1] * cv[i][1][1] + cw[i][2] * cv[i][2][1] + cw[i][3] * cv[i][3][1]) * mk;
       _Float16 hv[8], lv[8];
@@ -369,12 +381,12 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   load_b(0);
   load_w(wh[0], wl[0], 0);
   load_w(wh[1], wl[1], 1);
-  store_b(smem, 0);
+  store_b(smem);
   if (p.n_chunks > 1) load_b(1);
   __syncthreads();
-  // (no sched_barrier pinning here, unlike the conv kernels: with it the <2,2,1> instance produced
-  //  rare 4-pixel glitches when launched behind an unrelated kernel - tools/dbg_det2.py - while this
-  //  form is clean under the same stress)
+  // (no sched_barrier pinning here: it buys nothing in this kernel - the staging VALU work, not the
+  //  prefetch distance, is the bound - and an earlier form with exec-masked corner loads glitched
+  //  with it when launched behind unrelated kernels, see tools/stress_dcn.py)
   for (int c = 0; c < p.n_chunks; ++c) {
     unsigned char* cur = smem + (c & 1) * BUF;
     unsigned char* nxt = smem + ((c + 1) & 1) * BUF;
@@ -383,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     mma_kstep(cur, 1, wh[1], wl[1]);
     if (c + 1 < p.n_chunks) {
       load_w(wh[1], wl[1], 2 * c + 3);
-      store_b(nxt, c + 1);
+      store_b(nxt);
       if (c + 2 < p.n_chunks) load_b(c + 2);
     }
     __syncthreads();
@@ -490,7 +502,7 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   CF_REQUIRE(a->act == CF_ACT_NONE || a->act == CF_ACT_RELU, "cf_dcn_v2_f16x3: act=%d unsupported", a->act);
   CF_REQUIRE(a->out_scale > 0.0f, "cf_dcn_v2_f16x3: out_scale missing");
   const long M = (long)a->B * a->H * a->W;
-  CF_REQUIRE(M > 0 && M < (1L << 31), "cf_dcn_v2_f16x3: bad geometry");
+  CF_REQUIRE(M > 0 && M * a->C < (1L << 31), "cf_dcn_v2_f16x3: bad geometry / tensor too large");
   DcnF k{};
   k.x = a->x; k.om = a->offmask; k.weight = reinterpret_cast<const unsigned char*>(a->weight);
   k.bias = a->bias; k.out = a->out;

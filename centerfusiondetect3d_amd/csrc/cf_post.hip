@@ -233,6 +233,7 @@ __global__ __launch_bounds__(TOPK_MERGE_THREADS) void topk_merge_kernel(const ui
 // Frustum association
 // ---------------------------------------------------------------------------------------------
 constexpr int FR_THREADS = 1024;
+constexpr int FR_SPLIT = 8;         // workgroups per image (pixel shares of the paint pass)
 constexpr int FR_MAXK = 256;
 
 __device__ __forceinline__ void py_slice(int start, int stop, int n, int& s, int& e) {
@@ -266,7 +267,10 @@ __global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
     const float* __restrict__ pc_dep, int H, int W, float max_pc_dist, float* __restrict__ pc_hm,
     float* __restrict__ pc_hm_nhwc4, unsigned* __restrict__ pc_hm_split8) {
   __shared__ FrBox box[FR_MAXK];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // FR_SPLIT workgroups per image: each rebuilds the (cheap) box table and paints its share of the
+  // pixels - the per-pixel "last covering hit" scan is what takes the time
+  const int b = blockIdx.x / FR_SPLIT, part = blockIdx.x % FR_SPLIT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HW = H * W;
   const float* dep_b = depth + (size_t)b * HW;
   const float* wh_b = wh + (size_t)b * 2 * HW;
@@ -363,7 +367,9 @@ __global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
 
   // ---- paint: boxes are drawn in top-k order, so for every pixel the LAST covering hit wins
   float* hm = pc_hm + (size_t)b * 3 * HW;
-  for (int p = tid; p < HW; p += FR_THREADS) {
+  const int p_len = (HW + FR_SPLIT - 1) / FR_SPLIT;
+  const int p_end = min(HW, (part + 1) * p_len);
+  for (int p = part * p_len + tid; p < p_end; p += FR_THREADS) {
     const int y = p / W, x = p - y * W;
     float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
     for (int i = K - 1; i >= 0; --i) {
@@ -677,7 +683,7 @@ extern "C" int cf_frustum_assoc(const int32_t* inds, int K, const float* depth, 
   CF_REQUIRE(inds && depth && wh && dim && rot && calib && pc_dep && pc_hm, "cf_frustum_assoc: null buffer");
   CF_REQUIRE(K >= 1 && K <= FR_MAXK, "cf_frustum_assoc: K=%d outside [1,%d]", K, FR_MAXK);
   CF_REQUIRE(B > 0 && H > 0 && W > 0, "cf_frustum_assoc: bad geometry");
-  hipLaunchKernelGGL(frustum_kernel, dim3(B), dim3(FR_THREADS), 0, (hipStream_t)stream, inds, K, depth, wh, dim,
+  hipLaunchKernelGGL(frustum_kernel, dim3(B * FR_SPLIT), dim3(FR_THREADS), 0, (hipStream_t)stream, inds, K, depth, wh, dim,
                      rot, calib, pc_dep, H, W, max_pc_dist, pc_hm, pc_hm_nhwc4,
                      static_cast<unsigned*>(pc_hm_split8));
   return cf_check_launch("cf_frustum_assoc");
