@@ -104,16 +104,13 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
       const int u = tid + 256 * it;
       const int row = u / UPR, q = u % UPR;
       if (row < p.PR) {
-        _Float16 hv[4], lv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xx = __builtin_amdgcn_fmed3f(raw[it][e] * ASCALE, -65504.0f, 65504.0f);
-          hv[e] = (_Float16)xx;
-          lv[e] = (_Float16)(xx - (float)hv[e]);
-        }
+        const f32x4 xs = raw[it] * ASCALE;
+        uint2 hi, lo;
+        split2(xs[0], xs[1], hi.x, lo.x);
+        split2(xs[2], xs[3], hi.y, lo.y);
         unsigned char* o = buf + row * ROWB + (q >> 2) * 64 + (q & 3) * 8;
-        *reinterpret_cast<uint2*>(o) = uint2{pack_h2(hv[0], hv[1]), pack_h2(hv[2], hv[3])};
-        *reinterpret_cast<uint2*>(o + 32) = uint2{pack_h2(lv[0], lv[1]), pack_h2(lv[2], lv[3])};
+        *reinterpret_cast<uint2*>(o) = hi;
+        *reinterpret_cast<uint2*>(o + 32) = lo;
       }
     }
   };

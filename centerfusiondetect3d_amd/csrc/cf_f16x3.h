@@ -11,25 +11,31 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr float ASCALE = 16.0f;   // activation pre-scale (2^4), undone by out_scale
 constexpr int FROWB = 80;         // LDS bytes per pixel row per plane: 32 f16 + 16 B pad
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
   return ((unsigned)__builtin_bit_cast(unsigned short, b) << 16) | __builtin_bit_cast(unsigned short, a);
 }
 
+// two ALREADY SCALED fp32 values -> clamped, split into packed fp16 hi / lo pairs.  Written on
+// 2-vectors so gfx950's packed converts are used (v_cvt_pk_f16_f32, v_pk_add_f32): 4 VALU
+// instructions per value including the clamp, and no separate packing.
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const f32x2 x = {__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f)};
+  const f16x2 h = __builtin_convertvector(x, f16x2);
+  const f16x2 l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2), f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
 // 8 fp32 -> scaled, clamped, split into fp16 hi / lo (4 dwords each)
 __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4& hi, u32x4& lo) {
-  _Float16 h[8], l[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float x = (e < 4 ? v0[e] : v1[e - 4]) * ASCALE;
-    x = fminf(fmaxf(x, -65504.0f), 65504.0f);
-    h[e] = (_Float16)x;
-    l[e] = (_Float16)(x - (float)h[e]);
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    hi[e] = pack_h2(h[2 * e], h[2 * e + 1]);
-    lo[e] = pack_h2(l[2 * e], l[2 * e + 1]);
-  }
+  const f32x4 a = v0 * ASCALE, b = v1 * ASCALE;
+  { unsigned th, tl; split2(a[0], a[1], th, tl); hi[0] = th; lo[0] = tl; }
+  { unsigned th, tl; split2(a[2], a[3], th, tl); hi[1] = th; lo[1] = tl; }
+  { unsigned th, tl; split2(b[0], b[1], th, tl); hi[2] = th; lo[2] = tl; }
+  { unsigned th, tl; split2(b[2], b[3], th, tl); hi[3] = th; lo[3] = tl; }
 }
 
 __device__ __forceinline__ const f16x8* wfrag16(const unsigned char* w, int rt, int ks, int plane, int n_ks, int lane) {

@@ -321,21 +321,21 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     for (int i = 0; i < WP; ++i) {
       const int pr = tid + 256 * i;
       const float mk = cmk[i];   // the mask (x 2^4 activation scale) is applied after the 4-corner sum, as the reference does
-      f32x4 v0 = (cw[i][0] * cv[i][0][0] + cw[i][1] * cv[i][1][0] + cw[i][2] * cv[i][2][0] + cw[i][3] * cv[i][3][0]) * mk;
-      f32x4 v1 = (cw[i][0] * cv[i][0][1] + cw[i][1] * cv[i][1][1] + cw[i][2] * cv[i][2][1] + cw[i][3] * cv[i][3][1]) * mk;
-      _Float16 hv[8], lv[8];
+      // explicit vector FMAs (v_pk_fma_f32: two channels per instruction)
+      f32x4 v0 = cw[i][0] * cv[i][0][0], v1 = cw[i][0] * cv[i][0][1];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float xx = __builtin_amdgcn_fmed3f(e < 4 ? v0[e] : v1[e - 4], -65504.0f, 65504.0f);
-        hv[e] = (_Float16)xx;
-        lv[e] = (_Float16)(xx - (float)hv[e]);
+      for (int k = 1; k < 4; ++k) {
+        const f32x4 wk = {cw[i][k], cw[i][k], cw[i][k], cw[i][k]};
+        v0 = __builtin_elementwise_fma(wk, cv[i][k][0], v0);
+        v1 = __builtin_elementwise_fma(wk, cv[i][k][1], v1);
       }
-      u32x4 hi, lo;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        hi[e] = pack_h2(hv[2 * e], hv[2 * e + 1]);
-        lo[e] = pack_h2(lv[2 * e], lv[2 * e + 1]);
-      }
+      v0 *= mk;
+      v1 *= mk;
+      u32x4 hi, lo;                 // (the activation scale is already in mk)
+      { unsigned th, tl; split2(v0[0], v0[1], th, tl); hi[0] = th; lo[0] = tl; }
+      { unsigned th, tl; split2(v0[2], v0[3], th, tl); hi[1] = th; lo[1] = tl; }
+      { unsigned th, tl; split2(v1[0], v1[1], th, tl); hi[2] = th; lo[2] = tl; }
+      { unsigned th, tl; split2(v1[2], v1[3], th, tl); hi[3] = th; lo[3] = tl; }
       unsigned char* o = buf + (pr >> 2) * FROWB + (pr & 3) * 16;
       *reinterpret_cast<u32x4*>(o) = hi;
       *reinterpret_cast<u32x4*>(o + PLANE) = lo;

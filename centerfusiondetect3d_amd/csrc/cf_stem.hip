@@ -58,15 +58,9 @@ __device__ __forceinline__ const f16x8* sfrag(const unsigned char* w, int idx, i
 
 // 4 fp32 (one pixel, 4 consecutive channels) -> scaled, clamped fp16 hi / lo pairs
 __device__ __forceinline__ void split4(const f32x4v& v, uint2& hi, uint2& lo) {
-  _Float16 h[4], l[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float xx = __builtin_amdgcn_fmed3f(v[e] * ASCALE, -65504.0f, 65504.0f);
-    h[e] = (_Float16)xx;
-    l[e] = (_Float16)(xx - (float)h[e]);
-  }
-  hi = uint2{pack_h2(h[0], h[1]), pack_h2(h[2], h[3])};
-  lo = uint2{pack_h2(l[0], l[1]), pack_h2(l[2], l[3])};
+  const f32x4v xs = v * ASCALE;
+  split2(xs[0], xs[1], hi.x, lo.x);
+  split2(xs[2], xs[3], hi.y, lo.y);
 }
 
 __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
