@@ -11,8 +11,9 @@ from .model import DLASeg, getModel
 from .decode import fusionDecode, decode_packed, unpack_detections, DET_FIELDS, DET_WIDTH
 from .pointcloud import getPcFrustumHeatmap, getAffineTransform, process_point_cloud_batch
 from .postprocess import postProcess, post_process_packed, unpack_post, POST_FIELDS, POST_WIDTH
+from .preprocess import preProcessImages
 
-__all__ = ["CfgNode", "centerfusion_middle_config", "centernet_config", "update_heads", "DLASeg",
+__all__ = ["preProcessImages", "CfgNode", "centerfusion_middle_config", "centernet_config", "update_heads", "DLASeg",
            "getModel", "fusionDecode", "decode_packed", "unpack_detections", "DET_FIELDS",
            "DET_WIDTH", "getPcFrustumHeatmap", "getAffineTransform", "process_point_cloud_batch", "postProcess",
            "post_process_packed", "unpack_post", "POST_FIELDS", "POST_WIDTH"]

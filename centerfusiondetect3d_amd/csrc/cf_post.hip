@@ -639,6 +639,53 @@ __global__ __launch_bounds__(PL_THREADS) void pillar_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Image side of Detector.pre_process (detector.py:226-234): cv2.warpAffine(INTER_LINEAR, constant
+// border 0) of the uint8 camera frame in OpenCV's fixed-point arithmetic (10-bit coordinates, 5-bit
+// bilinear fractions, 15-bit weights: oracle/preprocess_ref.py states it), then
+// ((v / 255.0 - mean) / std) in float64 -> fp32, HWC -> CHW.  One thread per output pixel.
+// (This file is built with -ffp-contract=off: M1*y + M2 must round twice, as it does in OpenCV.)
+// ---------------------------------------------------------------------------------------------
+struct PreK {
+  const uint8_t* src;   // (B, Hs, Ws, 3)
+  float* out;           // (B, 3, Hd, Wd)
+  double m[6];          // dst -> src map (already inverted)
+  double mean[3], stdv[3];
+  int B, Hs, Ws, Hd, Wd;
+};
+
+__global__ __launch_bounds__(256) void preprocess_kernel(PreK p) {
+  const long total = (long)p.B * p.Hd * p.Wd;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % p.Wd);
+    const long r = i / p.Wd;
+    const int y = (int)(r % p.Hd), b = (int)(r / p.Hd);
+    const int X0 = __double2int_rn((p.m[1] * (double)y + p.m[2]) * 1024.0) + 16;
+    const int Y0 = __double2int_rn((p.m[4] * (double)y + p.m[5]) * 1024.0) + 16;
+    const int X = (X0 + __double2int_rn(p.m[0] * (double)x * 1024.0)) >> 5;
+    const int Y = (Y0 + __double2int_rn(p.m[3] * (double)x * 1024.0)) >> 5;
+    const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+    const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32;
+    const int w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    const uint8_t* img = p.src + (size_t)b * p.Hs * p.Ws * 3;
+    const bool y0 = (unsigned)sy < (unsigned)p.Hs, y1 = (unsigned)(sy + 1) < (unsigned)p.Hs;
+    const bool x0 = (unsigned)sx < (unsigned)p.Ws, x1 = (unsigned)(sx + 1) < (unsigned)p.Ws;
+    const uint8_t* p00 = img + ((size_t)(y0 ? sy : 0) * p.Ws + (x0 ? sx : 0)) * 3;
+    const uint8_t* p01 = img + ((size_t)(y0 ? sy : 0) * p.Ws + (x1 ? sx + 1 : 0)) * 3;
+    const uint8_t* p10 = img + ((size_t)(y1 ? sy + 1 : 0) * p.Ws + (x0 ? sx : 0)) * 3;
+    const uint8_t* p11 = img + ((size_t)(y1 ? sy + 1 : 0) * p.Ws + (x1 ? sx + 1 : 0)) * 3;
+    const int m00 = (y0 && x0) ? w00 : 0, m01 = (y0 && x1) ? w01 : 0;
+    const int m10 = (y1 && x0) ? w10 : 0, m11 = (y1 && x1) ? w11 : 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int acc = p00[c] * m00 + p01[c] * m01 + p10[c] * m10 + p11[c] * m11;
+      const int v = (acc + (1 << 14)) >> 15;
+      const double n = ((double)v / 255.0 - p.mean[c]) / p.stdv[c];
+      p.out[(((size_t)b * 3 + c) * p.Hd + y) * p.Wd + x] = (float)n;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" size_t cf_topk_workspace_bytes(int B, int K) {
@@ -726,4 +773,25 @@ extern "C" int cf_pillar_expand(const double* pc_2d, const double* pc_3d, const 
                      max_n, n_rows, calib, trans, H, W, pillar_h, pillar_w, pillar_l, pc_dep, keep_mask, xy_out,
                      band_rows);
   return cf_check_launch("cf_pillar_expand");
+}
+
+extern "C" int cf_preprocess_images(const uint8_t* src, int B, int Hs, int Ws, const double* map_dst_to_src,
+                                    const float* mean, const float* stdv, int Hd, int Wd, float* out, void* stream) {
+  CF_REQUIRE(src && map_dst_to_src && mean && stdv && out, "cf_preprocess_images: null buffer");
+  CF_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, "cf_preprocess_images: bad geometry");
+  CF_REQUIRE(Hs < 32768 && Ws < 32768 && Hd < 32768 && Wd < 32768, "cf_preprocess_images: image too large for the fixed-point map");
+  PreK k{};
+  k.src = src; k.out = out;
+  for (int i = 0; i < 6; ++i) k.m[i] = map_dst_to_src[i];        // host memory: six doubles
+  for (int c = 0; c < 3; ++c) {
+    CF_REQUIRE(stdv[c] != 0.0f, "cf_preprocess_images: std[%d] is zero", c);
+    k.mean[c] = (double)mean[c];
+    k.stdv[c] = (double)stdv[c];
+  }
+  k.B = B; k.Hs = Hs; k.Ws = Ws; k.Hd = Hd; k.Wd = Wd;
+  const long total = (long)B * Hd * Wd;
+  const long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
+                     (hipStream_t)stream, k);
+  return cf_check_launch("cf_preprocess_images");
 }

@@ -222,6 +222,14 @@ int cf_nchw_to_nhwc4(const float* x, float* out, int B, int C, int H, int W, voi
 int cf_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, int C, int c_stride,
                     void* stream);
 
+/* cf_preprocess_images: the image side of Detector.pre_process (detector.py:226-234; SURVEY §8(f)
+ * rank 2): cv2.warpAffine(INTER_LINEAR, border 0) of uint8 HWC camera frames to the network input
+ * size in OpenCV's fixed-point arithmetic, ((v / 255 - mean) / std) evaluated in float64, fp32 NCHW out.
+ * src (B, Hs, Ws, 3) uint8 on the device; map_dst_to_src, mean, stdv: HOST pointers (six doubles: the
+ * already inverted 2x3 matrix, as cv::warpAffine forms it; three floats each). */
+int cf_preprocess_images(const uint8_t* src, int B, int Hs, int Ws, const double* map_dst_to_src,
+                         const float* mean, const float* stdv, int Hd, int Wd, float* out, void* stream);
+
 /* cf_topk_peaks: per-image top-K over a (B,C,H,W) NCHW score map, optionally after the 3x3
  * equality NMS, ordered by (score desc, class asc, pixel asc).
  * replaces model/utils.py:6-38 (topk) [+ model/utils.py:112-128 (nms) when nms != 0].

@@ -620,3 +620,27 @@ def test_stem_fused(dev, B, C, H, W):
     err32 = float((t32.double() - ref).abs().max() / ref.abs().max())
     print(f"[stem] {B}x{C}x{H}x{W}: max|err|/max|ref| = {err:.2e} (torch fp32 chain: {err32:.2e})")
     assert err < 2e-6, err
+
+
+# ------------------------------------------------------------------------- image pre-processing
+@pytest.mark.parametrize("B,Hs,Ws,inH,inW,M", [
+    (2, 900, 1600, 448, 800, None),                                   # nuScenes: the detector's own matrix
+    (1, 90, 160, 64, 96, [[0.61, 0.0, -2.3], [0.0, 0.61, 4.75]]),     # real bilinear blending + borders
+    (3, 37, 53, 32, 64, [[1.13, 0.21, -3.5], [-0.17, 0.94, 6.25]]),   # rotation / shear, much of it outside
+    (1, 16, 16, 16, 16, [[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]]),          # identity
+])
+def test_preprocess_images_bit_exact_vs_oracle(dev, B, Hs, Ws, inH, inW, M):
+    from centerfusiondetect3d_amd import preProcessImages, getAffineTransform
+    from centerfusiondetect3d_amd.preprocess import NUSCENES_MEAN, NUSCENES_STD
+    from oracle import preprocess_ref
+    frames = [np.random.RandomState(7 + i).randint(0, 256, size=(Hs, Ws, 3)).astype(np.uint8) for i in range(B)]
+    Mh = np.array(M) if M is not None else getAffineTransform(np.array([Ws / 2.0, Hs / 2.0], np.float32),
+                                                              max(Hs, Ws) * 1.0, 0, [inW, inH])
+    ref = preprocess_ref.pre_process_images(frames, Mh, (inH, inW), NUSCENES_MEAN, NUSCENES_STD)
+    got = preProcessImages(frames, (inH, inW), transMat=M, device=dev)
+    assert got.shape == (B, 3, inH, inW) and got.dtype == torch.float32 and got.is_cuda
+    assert np.array_equal(got.cpu().numpy(), ref)
+    if M is None:   # 1600x900 -> 800x448 is an exact 2x decimation: rows 2y + 2, columns 2x
+        raw = np.stack(frames)[:, 2:898:2, 0:1600:2].astype(np.float64)
+        exp = ((raw / 255.0 - NUSCENES_MEAN) / NUSCENES_STD).astype(np.float32).transpose(0, 3, 1, 2)
+        assert np.array_equal(ref, exp)
