@@ -81,6 +81,7 @@ SYMBOLS = {
     "cf_maxpool2x2": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "cf_nchw_to_nhwc4": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "cf_nhwc_to_nchw": (_i, [_f, _f, _i, _i, _i, _i, _i, _f]),
+    "cf_radar_ingest": (_i, [_f, _f, _i, _i, _i, _f, _i, _i, _d, _d, _i, _f, _f, _f, _f]),
     "cf_preprocess_images": (_i, [_f, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_float),
                                  C.POINTER(C.c_float), _i, _i, _f, _f]),
     "cf_topk_workspace_bytes": (C.c_size_t, [_i, _i]),

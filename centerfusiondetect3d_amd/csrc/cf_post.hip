@@ -686,6 +686,75 @@ __global__ __launch_bounds__(256) void preprocess_kernel(PreK p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Radar ingest (detector.py:257-283, nuscenes.py:171-199, pointcloud.py:17-49):
+// raw sweep (R rows x N points, float64, camera frame) -> depth gate, y offset, pinhole projection,
+// image-border gate, depth order -> the padded pc_2d / pc_3d / counts that cf_pillar_expand consumes.
+// One workgroup per frame, one thread per point; the order is a rank by counting over LDS
+// (depth, then original index: a stable sort; N <= 1024 so N^2 comparisons are a few microseconds).
+// Arithmetic order as oracle/radar_ref.py fixes it (products summed left to right, no FMA).
+// ---------------------------------------------------------------------------------------------
+constexpr int RI_MAXN = 1024;
+
+__global__ __launch_bounds__(RI_MAXN) void radar_ingest_kernel(
+    const double* __restrict__ pc, const int32_t* __restrict__ counts_in, int R, int max_n,
+    const double* __restrict__ intr, double width, double height, double max_dist, double z_offset,
+    int descending, double* __restrict__ pc_2d, double* __restrict__ pc_3d, int32_t* __restrict__ counts_out) {
+  __shared__ double s_depth[RI_MAXN];
+  __shared__ int s_keep[RI_MAXN];
+  __shared__ int s_total;
+  const int b = blockIdx.x, i = threadIdx.x;
+  const int n = min(counts_in[b], max_n);
+  const double* src = pc + (size_t)b * R * max_n;
+  const double* K = intr + (size_t)b * 9;
+  if (i == 0) s_total = 0;
+  bool keep = false;
+  double u = 0.0, v = 0.0, z = 0.0, y = 0.0;
+  if (i < n) {
+    const double x = src[i];
+    y = src[(size_t)max_n + i];
+    z = src[(size_t)2 * max_n + i];
+    keep = !(max_dist > 0.0) || z <= max_dist;
+    if (z_offset != 0.0) y -= z_offset;
+    const double px = K[0] * x + K[1] * y + K[2] * z;
+    const double py = K[3] * x + K[4] * y + K[5] * z;
+    const double pz = K[6] * x + K[7] * y + K[8] * z;
+    u = px / pz;
+    v = py / pz;
+    keep = keep && z > 0.0 && u > 1.0 && u < width - 1.0 && v > 1.0 && v < height - 1.0;
+  }
+  s_depth[i] = z;
+  s_keep[i] = keep ? 1 : 0;
+  __syncthreads();
+  if (keep) {
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const double dj = s_depth[j];
+      rank += (s_keep[j] && (dj < z || (dj == z && j < i))) ? 1 : 0;
+    }
+    atomicAdd(&s_total, 1);
+    s_keep[i] = rank + 1;                  // (every thread has read s_keep[i] only as a flag: still non-zero)
+  }
+  __syncthreads();
+  const int total = s_total;
+  if (i == 0) counts_out[b] = total;
+  double* o2 = pc_2d + (size_t)b * 3 * max_n;
+  double* o3 = pc_3d + (size_t)b * R * max_n;
+  if (keep) {
+    const int rank = s_keep[i] - 1;
+    const int pos = descending ? total - 1 - rank : rank;
+    o2[pos] = u;
+    o2[(size_t)max_n + pos] = v;
+    o2[(size_t)2 * max_n + pos] = z;
+    for (int r = 0; r < R; ++r) o3[(size_t)r * max_n + pos] = (r == 1) ? y : src[(size_t)r * max_n + i];
+  }
+  // zero the padding so the output is fully defined
+  for (int j = total + i; j < max_n; j += RI_MAXN) {
+    o2[j] = 0.0; o2[(size_t)max_n + j] = 0.0; o2[(size_t)2 * max_n + j] = 0.0;
+    for (int r = 0; r < R; ++r) o3[(size_t)r * max_n + j] = 0.0;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t cf_topk_workspace_bytes(int B, int K) {
@@ -794,4 +863,16 @@ extern "C" int cf_preprocess_images(const uint8_t* src, int B, int Hs, int Ws, c
   hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
                      (hipStream_t)stream, k);
   return cf_check_launch("cf_preprocess_images");
+}
+
+extern "C" int cf_radar_ingest(const double* pc, const int32_t* counts_in, int B, int n_rows, int max_n,
+                               const double* intrinsics, int img_w, int img_h, double max_dist, double z_offset,
+                               int descending, double* pc_2d, double* pc_3d, int32_t* counts_out, void* stream) {
+  CF_REQUIRE(pc && counts_in && intrinsics && pc_2d && pc_3d && counts_out, "cf_radar_ingest: null buffer");
+  CF_REQUIRE(B > 0 && n_rows >= 3 && img_w > 2 && img_h > 2, "cf_radar_ingest: bad geometry");
+  CF_REQUIRE(max_n >= 1 && max_n <= RI_MAXN, "cf_radar_ingest: max_n=%d outside [1,%d]", max_n, RI_MAXN);
+  hipLaunchKernelGGL(radar_ingest_kernel, dim3(B), dim3(RI_MAXN), 0, (hipStream_t)stream, pc, counts_in, n_rows,
+                     max_n, intrinsics, (double)img_w, (double)img_h, max_dist, z_offset, descending, pc_2d, pc_3d,
+                     counts_out);
+  return cf_check_launch("cf_radar_ingest");
 }

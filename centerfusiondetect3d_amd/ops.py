@@ -345,3 +345,21 @@ def stem_fused(ps, x, out=None):
     a = stem_args(ps, x.contiguous(), out)
     _lib.check(_lib.load().cf_stem_fused(C.byref(a), _lib.stream_ptr()), "cf_stem_fused")
     return out
+
+
+def radar_ingest(pc, counts, intrinsics, img_wh, max_dist=60.0, z_offset=0.0, descending=False):
+    """pc (B,R,Nmax) f64 padded raw sweeps, counts (B) i32, intrinsics (B,3,3) f64 ->
+    pc_2d (B,3,Nmax) f64, pc_3d (B,R,Nmax) f64, counts_out (B) i32 - the inputs of pillar_expand."""
+    _need_cuda(pc, counts, intrinsics)
+    for t, dt in ((pc, torch.float64), (counts, torch.int32), (intrinsics, torch.float64)):
+        if t.dtype != dt or not t.is_contiguous():
+            raise _lib.CfHipError("cf_radar_ingest: wrong dtype / non-contiguous input")
+    B, R, max_n = pc.shape
+    pc_2d = torch.empty((B, 3, max_n), device=pc.device, dtype=torch.float64)
+    pc_3d = torch.empty((B, R, max_n), device=pc.device, dtype=torch.float64)
+    cnt = torch.empty((B,), device=pc.device, dtype=torch.int32)
+    _lib.check(_lib.load().cf_radar_ingest(pc.data_ptr(), counts.data_ptr(), B, R, max_n, intrinsics.data_ptr(),
+                                           int(img_wh[0]), int(img_wh[1]), float(max_dist), float(z_offset),
+                                           int(bool(descending)), pc_2d.data_ptr(), pc_3d.data_ptr(), cnt.data_ptr(),
+                                           _lib.stream_ptr()), "cf_radar_ingest")
+    return pc_2d, pc_3d, cnt

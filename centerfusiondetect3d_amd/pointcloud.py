@@ -58,3 +58,27 @@ def process_point_cloud_batch(pc_2d_list, pc_3d_list, calibs, trans_out, out_hw,
     trans = np.broadcast_to(np.asarray(trans_out, np.float64), (B, 2, 3)).copy()
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     return ops.pillar_expand(t(p2), t(p3), t(cnt), t(calibs), t(trans), out_hw, pillar_dims)
+
+
+def radar_to_pc_dep(radar_pcs, intrinsics, img_wh, calibs, trans_out, out_hw, max_dist=60.0, z_offset=0.0,
+                    pillar_dims=(1.5, 0.2, 0.2), descending=False, device="cuda", max_points=1024):
+    """Whole radar side of `Detector.pre_process` on the device (detector.py:257-292): raw per-frame
+    sweeps (R x N float64 arrays as unpickled from annotations/radar_pc/<sensor>/<token>.bin, rows
+    0..2 = x, y, z in the camera frame) -> depth gate, z offset, image projection + border gate, depth
+    sort (cf_radar_ingest) -> pillar expansion (cf_pillar_expand) -> pc_dep (B,3,H,W) fp32.  Only the raw
+    points cross PCIe; nothing is filtered, projected or sorted on the host."""
+    B = len(radar_pcs)
+    arrs = [np.asarray(p, np.float64) for p in radar_pcs]
+    n_rows = max(10, max(a.shape[0] for a in arrs))
+    max_n = max(1, max(a.shape[1] for a in arrs))
+    if max_n > max_points:
+        raise ValueError(f"{max_n} radar points in a frame exceeds the kernel limit {max_points}")
+    pc = np.zeros((B, n_rows, max_n)); cnt = np.zeros(B, np.int32)
+    for b, a in enumerate(arrs):
+        pc[b, :a.shape[0], :a.shape[1]], cnt[b] = a, a.shape[1]
+    K = np.ascontiguousarray(np.broadcast_to(np.asarray(intrinsics, np.float64).reshape(-1, 3, 3), (B, 3, 3)))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    pc_2d, pc_3d, counts = ops.radar_ingest(t(pc), t(cnt), t(K), img_wh, max_dist, z_offset, descending)
+    calibs = np.asarray(calibs, np.float64).reshape(B, 3, 4)
+    trans = np.broadcast_to(np.asarray(trans_out, np.float64), (B, 2, 3)).copy()
+    return ops.pillar_expand(pc_2d, pc_3d, counts, t(calibs), t(trans), out_hw, pillar_dims)

@@ -222,6 +222,17 @@ int cf_nchw_to_nhwc4(const float* x, float* out, int B, int C, int H, int W, voi
 int cf_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, int C, int c_stride,
                     void* stream);
 
+/* cf_radar_ingest: raw radar sweeps -> what cf_pillar_expand consumes (detector.py:257-283,
+ * datasets/nuscenes.py:171-199, utils/pointcloud.py:17-49): depth <= max_dist
+ * (if > 0), y -= z_offset, pinhole projection with the 3x3 intrinsic and division by the projected z,
+ * keep depth > 0 and 1 < u < img_w - 1 and 1 < v < img_h - 1, order by depth (ties: original index;
+ * descending = exact reverse).  pc (B, n_rows, max_n) f64 padded sweeps with counts_in (B) points each
+ * (rows 0..2 = x, y, z in the camera frame); intrinsics (B, 3, 3) f64.  Outputs: pc_2d (B, 3, max_n)
+ * [u, v, depth], pc_3d (B, n_rows, max_n) (row 1 carries the offset y), counts_out (B); padding zeroed. */
+int cf_radar_ingest(const double* pc, const int32_t* counts_in, int B, int n_rows, int max_n,
+                    const double* intrinsics, int img_w, int img_h, double max_dist, double z_offset,
+                    int descending, double* pc_2d, double* pc_3d, int32_t* counts_out, void* stream);
+
 /* cf_preprocess_images: the image side of Detector.pre_process (detector.py:226-234; SURVEY §8(f)
  * rank 2): cv2.warpAffine(INTER_LINEAR, border 0) of uint8 HWC camera frames to the network input
  * size in OpenCV's fixed-point arithmetic, ((v / 255 - mean) / std) evaluated in float64, fp32 NCHW out.

@@ -1,0 +1,57 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/__init__.py) - CPU restatement of the radar ingest between the
+on-disk sweep and `processPointCloud`:
+
+    reference src/lib/detector.py:257-283  (inference)   and   dataset/datasets/nuscenes.py:171-199
+    + utils/pointcloud.py:17-49 (map_pointcloud_to_image)
+
+    radar_pc (R x N float64, rows 0..2 = x, y, z in the camera frame)
+      -> keep depth <= MAX_PC_DIST           -> y -= PC_Z_OFFSET
+      -> project with the camera intrinsic, divide by the projected z (nuscenes `view_points(normalize=True)`)
+      -> keep depth > 0 and 1 < u < width - 1 and 1 < v < height - 1
+      -> order by depth (ascending; the training loader reverses it unless PC_REVERSE)
+
+PARITY UNPINNED: `view_points` lives in nuscenes-devkit, a third-party dependency that is absent from
+/root/reference and from this image (requirements.txt: `nuscenes-devkit`, unversioned); it is the
+documented homogeneous product `viewpad @ [p; 1]` followed by the division.  Two things the reference
+leaves to its libraries are fixed here, and the HIP kernel follows the same choices:
+  * the order of the three products of a projected coordinate - left to right, each rounded
+    (K0*x + K1*y + K2*z; numpy hands the 3x3 @ 3xN product to BLAS, whose summation order / FMA use is
+    not specified, so the last bit of u, v is not defined by the reference itself);
+  * ties in depth - `np.argsort` (quicksort) does not define their order; here the original index breaks
+    them (a stable sort), and the descending order is the exact reverse of the ascending one, as
+    `index[::-1]` makes it.
+Known-answer tests: tests/test_oracle_radar.py.
+"""
+import numpy as np
+
+
+def project(pc, K):
+    """(3, N) projected points [u, v, 1] = (K @ p) / (K @ p)[2], products summed left to right."""
+    K = np.asarray(K, np.float64)
+    x, y, z = pc[0], pc[1], pc[2]
+    px = K[0, 0] * x + K[0, 1] * y + K[0, 2] * z
+    py = K[1, 0] * x + K[1, 1] * y + K[1, 2] * z
+    pz = K[2, 0] * x + K[2, 1] * y + K[2, 2] * z
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.stack([px / pz, py / pz, pz / pz])
+
+
+def ingest_radar(radar_pc, cam_intrinsic, img_wh=(1600, 900), max_dist=60.0, z_offset=0.0, descending=False):
+    """-> pc_2d (3, M) [u, v, depth], pc_3d (R, M), both ordered by depth."""
+    pc = np.array(radar_pc, np.float64, copy=True)
+    if max_dist > 0:
+        pc = pc[:, pc[2] <= max_dist]
+    if z_offset != 0:
+        pc[1] -= z_offset
+    width, height = img_wh
+    depths = pc[2]
+    pts = project(pc[:3], cam_intrinsic)
+    with np.errstate(invalid="ignore"):
+        mask = (depths > 0) & (pts[0] > 1) & (pts[0] < width - 1) & (pts[1] > 1) & (pts[1] < height - 1)
+    pc_2d = pts[:, mask]
+    pc_2d[2] = depths[mask]
+    pc_3d = pc[:, mask]
+    order = np.argsort(pc_2d[2], kind="stable")
+    if descending:
+        order = order[::-1]
+    return pc_2d[:, order], pc_3d[:, order]
