@@ -40,8 +40,9 @@ struct Conv3F {
 // validity select and the tap offsets are compile-time constants.  Pays on wide maps (W = 200: 1.3x
 // input traffic instead of 2.6x) whenever W is close to a multiple of 16.
 template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2>
-__global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
-  static_assert(WC * WP * WK == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
+  constexpr int NT = 64 * WC * WP * WK;     // 4 waves, or 8 (WP doubled: two pixel groups share each weight fragment through L1)
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
   constexpr int R = 64 * WP;
   constexpr int PW2 = 18;                   // T2: patch width (16 + 2)
   constexpr int ROWB = 64 * WK + 16;        // per patch row: WK x (16 hi + 16 lo f16) + pad (odd multiple of 16 B)
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
   int goff[NU];                              // element offset of the unit in x for round 0, -1 = zeros
 #pragma unroll
   for (int it = 0; it < NU; ++it) {
-    const int u = tid + 256 * it;
+    const int u = tid + NT * it;
     const int row = u / UPR, q = u % UPR;
     if (T2) {
       const int y = ty0 - 1 + row / PW2, x = tx0 - 1 + row % PW2;
@@ -89,28 +90,33 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
       goff[it] = (row < p.PR && g >= 0 && g < p.M) ? g * p.x_stride + 4 * q : -1;
     }
   }
+  // the next round's patch is staged in two halves (loads of the first half fly over taps 0-3, those of
+  // the second over taps 4-8), so only half of the raw registers are live at any time
+  constexpr int NH0 = (NU + 1) / 2;
   f32x4 raw[NU];
-  auto load_patch = [&](int r) {
+  auto load_patch = [&](int r, int lo, int hi) {
     const int c0 = r * 16 * WK;
 #pragma unroll
     for (int it = 0; it < NU; ++it) {
+      if (it < lo || it >= hi) continue;
       raw[it] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (goff[it] >= 0) raw[it] = *reinterpret_cast<const f32x4*>(p.x + goff[it] + c0);
     }
   };
-  auto store_patch = [&](unsigned char* buf) {
+  auto store_patch = [&](unsigned char* buf, int lo, int hi) {
 #pragma unroll
     for (int it = 0; it < NU; ++it) {
-      const int u = tid + 256 * it;
+      if (it < lo || it >= hi) continue;
+      const int u = tid + NT * it;
       const int row = u / UPR, q = u % UPR;
       if (row < p.PR) {
         const f32x4 xs = raw[it] * ASCALE;
-        uint2 hi, lo;
-        split2(xs[0], xs[1], hi.x, lo.x);
-        split2(xs[2], xs[3], hi.y, lo.y);
+        uint2 hi2, lo2;
+        split2(xs[0], xs[1], hi2.x, lo2.x);
+        split2(xs[2], xs[3], hi2.y, lo2.y);
         unsigned char* o = buf + row * ROWB + (q >> 2) * 64 + (q & 3) * 8;
-        *reinterpret_cast<uint2*>(o) = hi;
-        *reinterpret_cast<uint2*>(o + 32) = lo;
+        *reinterpret_cast<uint2*>(o) = hi2;
+        *reinterpret_cast<uint2*>(o + 32) = lo2;
       }
     }
   };
@@ -161,35 +167,36 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
     }
   };
 
-  load_patch(0);
+  load_patch(0, 0, NU);
 #pragma unroll
   for (int t = 0; t < 3; ++t) load_w(wh[t], wl[t], wk * 9 + t);
-  store_patch(smem);
+  store_patch(smem, 0, NU);
   __syncthreads();
 
   for (int r = 0; r < p.n_rounds; ++r) {
     const unsigned char* cur = smem + (DB ? (r & 1) * bufb : 0);
     unsigned char* nxt = smem + (DB ? ((r + 1) & 1) * bufb : 0);
     const bool more = r + 1 < p.n_rounds;
-    if (more) load_patch(r + 1);
+    if (more) load_patch(r + 1, 0, NH0);
     const int ks0 = (r * WK + wk) * 9;
-    // B fragments one tap ahead (xf[t & 1]), weights three taps ahead; the sched_barrier after every
-    // tap keeps the compiler from sinking those prefetches back down to their first use
-    f16x8 xh[2][2], xl[2][2];
-    auto load_x = [&](f16x8 (&dh)[2], f16x8 (&dl)[2], int t, int toff) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int a = (T2 || ((vmask[ct] >> t) & 1u)) ? rowb[ct] + toff : zrow;
-        dh[ct] = *reinterpret_cast<const f16x8*>(cur + a);
-        dl[ct] = *reinterpret_cast<const f16x8*>(cur + a + 32);
-      }
-    };
+    // B fragments: the hi plane one tap ahead (xh[t & 1]), the lo plane - needed only by the third
+    // sweep - at the start of its tap; weights three taps ahead.  The sched_barrier after every tap
+    // keeps the compiler from sinking those prefetches back down to their first use
+    f16x8 xh[2][2], xl[2];
+    auto x_addr = [&](int ct, int t, int toff) { return (T2 || ((vmask[ct] >> t) & 1u)) ? rowb[ct] + toff : zrow; };
     int toff = 0;                            // ((t / 3) * W + t % 3) * ROWB, built incrementally
-    load_x(xh[0], xl[0], 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) xh[0][ct] = *reinterpret_cast<const f16x8*>(cur + x_addr(ct, 0, 0));
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) xl[ct] = *reinterpret_cast<const f16x8*>(cur + x_addr(ct, t, toff) + 32);
       toff += (t % 3 == 2) ? ((T2 ? PW2 : p.W) - 2) * ROWB : ROWB;
-      if (t + 1 < 9) load_x(xh[(t + 1) & 1], xl[(t + 1) & 1], t + 1, toff);
+      if (t + 1 < 9) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          xh[(t + 1) & 1][ct] = *reinterpret_cast<const f16x8*>(cur + x_addr(ct, t + 1, toff));
+      }
       // three independent sweeps over the tiles: no MFMA waits on the one issued just before it
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -205,13 +212,23 @@ __global__ __launch_bounds__(256, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-          accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t % 3][rt], xl[t & 1][ct], accs[rt][ct], 0, 0, 0);
+          accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t % 3][rt], xl[ct], accs[rt][ct], 0, 0, 0);
       // tap t+3 of this round, or tap t-6 of the next one (same set either way)
       load_w(wh[t % 3], wl[t % 3], t + 3 < 9 ? ks0 + t + 3 : ks0 + 9 * WK + t - 6);
+      if (DB && t == 3 && more) {            // first half of the next patch: split + store, then request the rest
+        store_patch(nxt, 0, NH0);
+        load_patch(r + 1, NH0, NU);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!DB) __syncthreads();                // single buffer: everyone is done reading it
-    if (more) store_patch(nxt);
+    if (!DB) {
+      __syncthreads();                       // single buffer: everyone is done reading it
+      if (more) {
+        store_patch(nxt, 0, NH0);
+        load_patch(r + 1, NH0, NU);
+      }
+    }
+    if (more) store_patch(nxt, NH0, NU);
     __syncthreads();
   }
 
@@ -298,7 +315,8 @@ bool try_launch(Conv3F k, int batch, hipStream_t st) {
     blocks = (k.M + R - 1) / R;
   }
   const long units = (long)k.PR * 4 * WK;
-  if (units > 256L * NU || blocks >= (1L << 31)) return false;
+  constexpr int NT = 64 * WC * WP * WK;
+  if (units > (long)NT * NU || blocks >= (1L << 31)) return false;
   size_t dyn = (size_t)(DB ? 2 : 1) * (k.PR + 1) * ROWB;
   if (WK > 1) dyn = dyn < (size_t)4 * RT * 2 * 16 * 64 * 4 ? (size_t)4 * RT * 2 * 16 * 64 * 4 : dyn;
   if (dyn > 160 * 1024) return false;
@@ -310,7 +328,7 @@ bool try_launch(Conv3F k, int batch, hipStream_t st) {
     limit = dyn < 65536 ? 65536 : dyn;
   }
   const dim3 grid((unsigned)blocks, (unsigned)((k.n_rt + WC * RT - 1) / (WC * RT)));
-  hipLaunchKernelGGL(kernel, grid, dim3(256), dyn, st, k);
+  hipLaunchKernelGGL(kernel, grid, dim3(NT), dyn, st, k);
   return true;
 }
 
@@ -375,9 +393,13 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
   } else if (a->N_pad == 64) {
     if (cfg(1)) ok = (t2 && try_launch<1, 4, 1, 2, 6, true, 2, true>(k, B, st)) || try_launch<1, 4, 1, 2, 6, true, 2>(k, B, st);
   } else if (a->N_pad == 128) {
-    if (cfg(1)) ok = try_launch<2, 2, 1, 2, 6, true, 2>(k, B, st);
+    if (cfg(1)) ok = try_launch<2, 2, 1, 2, 6, true, 2>(k, B, st);   // (8 waves x 256 pixels measured 4 % slower here)
   } else {
-    if (cfg(1)) ok = try_launch<4, 1, 1, 2, 4, true, 2>(k, B, st);
+    // 256+ channels: every 64-pixel tile streams the whole weight matrix from L2, which bounds these
+    // layers - with enough tiles to go round, 8 waves (two pixel groups per channel group, 128 pixels)
+    // halve that stream (the second group's fragment loads hit L1)
+    const long tiles128 = (M + 127) / 128 * ((a->N_pad + 255) / 256);
+    if (cfg(1)) ok = (tiles128 >= 160 && try_launch<4, 2, 1, 2, 2, true, 1>(k, B, st)) || try_launch<4, 1, 1, 2, 4, true, 2>(k, B, st);
   }
   if (!ok) return cf_conv2d_f16x3(a, stream);
   return cf_check_launch("cf_conv3x3_f16x3");

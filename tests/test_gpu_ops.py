@@ -535,6 +535,8 @@ def test_conv2d_f16x3_fp32_level_accuracy(dev, B, Ci, Co, H, W, k, stride, act, 
     (1, 64, 64, 112, 200, 1, True, True),     # level2 at the bench size: 16x16 tiles of one image (2-D patch)
     (2, 32, 27, 127, 127, 0, False, True),    # 2-D patch, last tile row / column one pixel short
     (1, 64, 64, 127, 126, 1, False, True),
+    (16, 256, 256, 28, 50, 1, True, True),    # level4 at the bench size: 8 waves, 128-pixel runs
+    (16, 128, 128, 56, 100, 1, True, True),   # level3 at the bench size: 8 waves, 256-pixel runs
 ])
 def test_conv3x3_f16x3_patch(dev, B, Ci, Co, H, W, act, res, exact):
     """LDS-patch 3x3 kernel: fp32-level accuracy against float64, and - where the K loop is not split
