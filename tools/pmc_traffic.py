@@ -6,7 +6,7 @@ FETCH_SIZE and WRITE_SIZE do not fit one pass):
 Units / corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: the counters are in
 KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide streaming reads at 64 B, so it is
 doubled; WRITE_SIZE is exact for 16-byte-per-lane stores."""
-import glob, json, re, sqlite3, sys
+import os, glob, json, re, sqlite3, sys
 
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
@@ -14,7 +14,7 @@ def short(n):
     return re.sub(r"\(.*$", "", n)
 
 def per_kernel(d, counter):
-    path = glob.glob(d + "/**/*.db", recursive=True)[0]
+    path = max(glob.glob(d + "/**/*.db", recursive=True), key=os.path.getmtime)
     c = sqlite3.connect(path)
     out = {}
     for name, total, n in c.execute("select kernel_name, sum(value), count(*) from counters_collection "

@@ -2,7 +2,7 @@
 bench.py (a step starts at the first kernel of the forward: the stem) and optionally its timeline.
     python tools/prof_db.py <results.db> [--timeline]
 """
-import glob, re, sqlite3, sys
+import os, glob, re, sqlite3, sys
 from collections import defaultdict
 
 def short(n):
@@ -12,7 +12,7 @@ def short(n):
 
 path = sys.argv[1]
 if not path.endswith(".db"):
-    path = glob.glob(path + "/**/*.db", recursive=True)[0]
+    path = max(glob.glob(path + "/**/*.db", recursive=True), key=os.path.getmtime)
 c = sqlite3.connect(path)
 rows = list(c.execute("select name, start, end from kernels order by start"))
 first = next(k for k in ("stem_kernel", "nchw_to_nhwc4") if any(k in r[0] for r in rows))
