@@ -7,24 +7,25 @@ namespace {
 
 // out[b][y][x][c] = sum_{ky,kx} x[b][(y+p-ky)/f][(x+p-kx)/f][c] * w[ky][kx][c]  (+ skip)
 // for the taps where (y+p-ky) and (x+p-kx) are multiples of f and in range; k = 2f, p = f/2, so
-// exactly two ky (and two kx) qualify per output pixel.
+// exactly two ky (and two kx) qualify per output pixel.  Grid = (row segments, output rows, images):
+// no per-element div / mod chain except the one split of the in-row index into (x, channel group);
+// F is a template constant (2 or 4: shifts), 0 = any even f.
+template <int F>
 __global__ __launch_bounds__(256) void upsample_dw_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ skip,
-                                                          float* __restrict__ out, int B, int H, int W,
-                                                          int C4, int f) {
+                                                          float* __restrict__ out, int H, int W, int C4, int f_rt) {
+  const int f = F ? F : f_rt;
   const int Ho = H * f, Wo = W * f, k = 2 * f, pad = f / 2;
-  const long total = (long)B * Ho * Wo * C4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    long pix = i / C4;
-    const int xo = (int)(pix % Wo);
-    pix /= Wo;
-    const int yo = (int)(pix % Ho);
-    const int b = (int)(pix / Ho);
+  const int yo = blockIdx.y, b = blockIdx.z;
+  const int ky0 = (yo + pad) % f;
+  const int row_len = Wo * C4;
+  const size_t row_base = ((size_t)b * Ho + yo) * row_len;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < row_len; j += gridDim.x * 256) {
+    const int xo = j / C4, c4 = j - xo * C4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (skip) acc = reinterpret_cast<const f32x4*>(skip)[i];
-    const int ky0 = (yo + pad) % f, kx0 = (xo + pad) % f;
+    if (skip) acc = reinterpret_cast<const f32x4*>(skip)[row_base + j];
+    const int kx0 = (xo + pad) % f;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const int ky = ky0 + a * f;
@@ -35,12 +36,12 @@ __global__ __launch_bounds__(256) void upsample_dw_kernel(const float* __restric
         const int kx = kx0 + bb * f;
         const int xi = (xo + pad - kx) / f;
         if (xi < 0 || xi >= W || kx >= k) continue;
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[((long)(b * H + yi) * W + xi) * C4 + c4];
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[((size_t)(b * H + yi) * W + xi) * C4 + c4];
         const f32x4 ww = reinterpret_cast<const f32x4*>(w)[(ky * k + kx) * C4 + c4];
         acc += v * ww;
       }
     }
-    reinterpret_cast<f32x4*>(out)[i] = acc;
+    reinterpret_cast<f32x4*>(out)[row_base + j] = acc;
   }
 }
 
@@ -107,9 +108,16 @@ extern "C" int cf_upsample_dw(const float* x, const float* weight, const float* 
   CF_REQUIRE(x && weight && out, "cf_upsample_dw: null buffer");
   CF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "cf_upsample_dw: bad geometry (C=%d)", C);
   CF_REQUIRE(f >= 2 && f % 2 == 0, "cf_upsample_dw: f=%d must be even (k=2f, pad=f/2)", f);
-  const long total = (long)B * H * f * W * f * (C / 4);
-  hipLaunchKernelGGL(upsample_dw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, weight,
-                     skip, out, B, H, W, C / 4, f);
+  CF_REQUIRE((long)H * f < 65536 && B < 65536, "cf_upsample_dw: too many rows / images for the launch grid");
+  const int row_len = W * f * (C / 4);
+  const dim3 grid((unsigned)((row_len + 255) / 256), (unsigned)(H * f), (unsigned)B);
+  hipStream_t st = (hipStream_t)stream;
+  if (f == 2)
+    hipLaunchKernelGGL(upsample_dw_kernel<2>, grid, dim3(256), 0, st, x, weight, skip, out, H, W, C / 4, f);
+  else if (f == 4)
+    hipLaunchKernelGGL(upsample_dw_kernel<4>, grid, dim3(256), 0, st, x, weight, skip, out, H, W, C / 4, f);
+  else
+    hipLaunchKernelGGL(upsample_dw_kernel<0>, grid, dim3(256), 0, st, x, weight, skip, out, H, W, C / 4, f);
   return cf_check_launch("cf_upsample_dw");
 }
 
