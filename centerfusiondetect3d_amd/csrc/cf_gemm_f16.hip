@@ -227,6 +227,8 @@ struct DcnF {
   float* out;
   int om_stride, H, W, C, n_chunks, chunks_per_tap, out_stride, act, M, N, n_rt;
   float out_scale;
+  unsigned* out_split;   // optional split-bf16 copy [M][2][split_stride] (as 32-bit words: 2 bf16 each)
+  int split_stride;
 };
 
 template <int WC, int WP, int RT>
@@ -421,6 +423,19 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
           }
           *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.out_stride + n) = v;
+          if (p.out_split) {   // hi = rne_bf16(v), lo = rne_bf16(v - hi): the head kernels' input format
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const __bf16 h0 = (__bf16)v[2 * e], h1 = (__bf16)v[2 * e + 1];
+              const __bf16 l0 = (__bf16)(v[2 * e] - (float)h0), l1 = (__bf16)(v[2 * e + 1] - (float)h1);
+              w[e] = ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16) | __builtin_bit_cast(unsigned short, h0);
+              w[2 + e] = ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16) | __builtin_bit_cast(unsigned short, l0);
+            }
+            unsigned* o = p.out_split + ((size_t)m * 2 * p.split_stride + n) / 2;
+            *reinterpret_cast<uint2*>(o) = uint2{w[0], w[1]};
+            *reinterpret_cast<uint2*>(o + p.split_stride / 2) = uint2{w[2], w[3]};
+          }
         } else {
           for (int e = 0; e < 4 && n + e < p.N; ++e) {
             float x = v[e] + p.bias[n + e];
@@ -512,6 +527,10 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   k.out_stride = a->out_stride; k.act = a->act; k.M = (int)M; k.N = a->N;
   k.n_rt = a->N_pad / 32;
   k.out_scale = a->out_scale;
+  k.out_split = static_cast<unsigned*>(a->out_split_bf16);
+  k.split_stride = a->split_stride;
+  CF_REQUIRE(!a->out_split_bf16 || (a->split_stride >= a->N && a->split_stride % 8 == 0 && a->N % 4 == 0),
+             "cf_dcn_v2_f16x3: split output needs N %% 4 == 0 and a plane stride >= N that is a multiple of 8");
   hipStream_t st = (hipStream_t)stream;
   if (a->N_pad <= 64) {          // 64 channels: 2 x 32-channel wave rows, 2 x 64 pixels
     launch_f16(dcn_f16x3_kernel<2, 2, 1>, dim3((unsigned)((M + 127) / 128), (unsigned)((a->N_pad + 63) / 64)), 0, st, k);

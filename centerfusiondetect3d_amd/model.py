@@ -329,7 +329,14 @@ class _Plan:
 
         if bf:
             feat_in = buf(B, h4, w4, 2, 64, dtype=torch.bfloat16)
-            self.steps.append((self.lib.cf_split_bf16, feat.data_ptr(), feat_in.data_ptr(), M4, 64, 64, 64))
+            # the split-bf16 copy of the feature map the heads read is written by the epilogue of the DCN
+            # that produces it (f16x3 kernel); a separate split pass only if that kernel is not in use
+            producer = [a for a in self.keep if isinstance(a, _lib.DcnArgs) and a.out == feat.data_ptr()
+                        and a.out_scale > 0 and a.N == 64]
+            if producer:
+                producer[-1].out_split_bf16, producer[-1].split_stride = feat_in.data_ptr(), 64
+            else:
+                self.steps.append((self.lib.cf_split_bf16, feat.data_ptr(), feat_in.data_ptr(), M4, 64, 64, 64))
         else:
             feat_in = feat
         hs = 256 * len(primary)

@@ -172,7 +172,7 @@ def run_head_tail(a):
 
 
 def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act=ACT_RELU,
-             precise=True):
+             precise=True, out_split=None):
     a = _lib.DcnArgs()
     a.x, a.offmask, a.om_stride = x.data_ptr(), offmask.data_ptr(), om_stride
     a.B, a.H, a.W, a.C = B, H, W, pd.c
@@ -180,6 +180,8 @@ def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act
     a.out, a.out_stride, a.act = out.data_ptr(), out_stride, act
     a.precise = int(bool(precise))
     a.out_scale = float(getattr(pd, "out_scale", 0.0))
+    if out_split is not None:            # (B,H,W,2,Cs) bf16: split copy for the head kernels (f16x3 kernel only)
+        a.out_split_bf16, a.split_stride = out_split.data_ptr(), out_split.shape[-1]
     return a
 
 

@@ -197,6 +197,9 @@ typedef struct cf_dcn_args {
   int32_t act;
   int32_t precise;      /* as cf_conv_args.precise              */
   float out_scale;      /* cf_dcn_v2_f16x3 only: 2^-(s+4)       */
+  void* out_split_bf16; /* cf_dcn_v2_f16x3 only, optional: the same result additionally as split-bf16 NHWC
+                           [B][H][W][2 (hi, lo)][split_stride] - what the head kernels read (saves cf_split_bf16) */
+  int32_t split_stride; /* channels per plane of out_split_bf16 (>= N, multiple of 8) */
 } cf_dcn_args;
 int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream);
 

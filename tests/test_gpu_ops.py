@@ -598,6 +598,12 @@ def test_dcn_v2_f16x3(dev, B, Ci, Co, H, W, mag):
     err = float((nchw(out).cpu().double() - ref).abs().max() / ref.abs().max())
     print(f"[dcn f16x3] C={Ci}->{Co}: max|err|/max|ref| = {err:.2e}")
     assert err < 5e-6, err
+    # optional second output: the same result as split-bf16 planes == cf_split_bf16 of the fp32 output
+    split = torch.full((B, H, W, 2, Co), float("nan"), device=dev, dtype=torch.bfloat16)
+    out2 = torch.empty_like(out)
+    a = ops.dcn_args(pd, nhwc(x).to(dev), om32.to(dev), 32, B, H, W, out2, Co, out_split=split)
+    ops.run_dcn(a)
+    assert torch.equal(out2, out) and torch.equal(split, ops.split_bf16(out))
 
 
 # ----------------------------------------------------------------------------------- fused stem
