@@ -28,7 +28,7 @@ class DcnArgs(C.Structure):
                 ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("weight", _f), ("bias", _f),
                 ("N", C.c_int32), ("N_pad", C.c_int32), ("out", _f), ("out_stride", C.c_int32),
                 ("act", C.c_int32), ("precise", C.c_int32), ("out_scale", C.c_float),
-                ("out_split_bf16", _f), ("split_stride", C.c_int32)]
+                ("out_split_bf16", _f), ("split_stride", C.c_int32), ("workspace", _f)]
 
 
 CF_MAX_HEADS = 12
@@ -78,6 +78,7 @@ SYMBOLS = {
     "cf_head_fused": (_i, [C.POINTER(HeadFusedArgs), _f]),
     "cf_dcn_v2_fused": (_i, [C.POINTER(DcnArgs), _f]),
     "cf_dcn_v2_f16x3": (_i, [C.POINTER(DcnArgs), _f]),
+    "cf_dcn_v2_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "cf_upsample_dw": (_i, [_f, _f, _f, _f, _i, _i, _i, _i, _i, _f]),
     "cf_maxpool2x2": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "cf_nchw_to_nhwc4": (_i, [_f, _f, _i, _i, _i, _i, _f]),

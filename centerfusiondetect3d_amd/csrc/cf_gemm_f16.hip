@@ -229,6 +229,7 @@ struct DcnF {
   float out_scale;
   unsigned* out_split;   // optional split-bf16 copy [M][2][split_stride] (as 32-bit words: 2 bf16 each)
   int split_stride;
+  float* partial;        // K split (gridDim.z > 1): raw partial sums [z][M][n_rt * 32], reduced by dcn_reduce_kernel
 };
 
 template <int WC, int WP, int RT>
@@ -380,27 +381,51 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
       }
   };
 
-  load_b(0);
-  load_w(wh[0], wl[0], 0);
-  load_w(wh[1], wl[1], 1);
+  // K split over gridDim.z (small maps with long K: 88 tiles x 144 chunks at 14x25 cannot fill the chip,
+  // and one tile's chunk chain is latency-bound): this workgroup owns chunks [c_lo, c_hi)
+  const int c_lo = (int)((long)p.n_chunks * blockIdx.z / gridDim.z);
+  const int c_hi = (int)((long)p.n_chunks * (blockIdx.z + 1) / gridDim.z);
+  load_b(c_lo);
+  load_w(wh[0], wl[0], 2 * c_lo);
+  load_w(wh[1], wl[1], 2 * c_lo + 1);
   store_b(smem);
-  if (p.n_chunks > 1) load_b(1);
+  if (c_lo + 1 < c_hi) load_b(c_lo + 1);
   __syncthreads();
   // (no sched_barrier pinning here: it buys nothing in this kernel - the staging VALU work, not the
   //  prefetch distance, is the bound - and an earlier form with exec-masked corner loads glitched
   //  with it when launched behind unrelated kernels, see tools/stress_dcn.py)
-  for (int c = 0; c < p.n_chunks; ++c) {
-    unsigned char* cur = smem + (c & 1) * BUF;
-    unsigned char* nxt = smem + ((c + 1) & 1) * BUF;
+  for (int c = c_lo; c < c_hi; ++c) {
+    unsigned char* cur = smem + ((c - c_lo) & 1) * BUF;
+    unsigned char* nxt = smem + ((c - c_lo + 1) & 1) * BUF;
     mma_kstep(cur, 0, wh[0], wl[0]);
-    if (c + 1 < p.n_chunks) load_w(wh[0], wl[0], 2 * c + 2);
+    if (c + 1 < c_hi) load_w(wh[0], wl[0], 2 * c + 2);
     mma_kstep(cur, 1, wh[1], wl[1]);
-    if (c + 1 < p.n_chunks) {
+    if (c + 1 < c_hi) {
       load_w(wh[1], wl[1], 2 * c + 3);
       store_b(nxt);
-      if (c + 2 < p.n_chunks) load_b(c + 2);
+      if (c + 2 < c_hi) load_b(c + 2);
     }
     __syncthreads();
+  }
+
+  if (gridDim.z > 1) {   // raw partial sums; scale / bias / activation happen in the reduction
+    const int ns = p.n_rt * 32;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int m = m0 + wp * 64 + ct * 32 + li;
+      if (m >= p.M || !w_ok) continue;
+      float* o = p.partial + ((size_t)blockIdx.z * p.M + m) * ns;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e];
+          *reinterpret_cast<f32x4*>(o + (rt0 + rt) * 32 + 8 * g + 4 * h) = v;
+        }
+    }
+    return;
   }
 
 #pragma unroll
@@ -445,6 +470,33 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
         }
       }
   }
+}
+
+// K-split reduction: out = act((sum_z partial[z]) * out_scale + bias), partials added in z order
+__global__ __launch_bounds__(256) void dcn_reduce_kernel(const float* __restrict__ partial, int ks, long MN4, int ns4,
+                                                         int N, const float* __restrict__ bias, float out_scale,
+                                                         int act, float* __restrict__ out, int out_stride) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < MN4; i += (long)gridDim.x * 256) {
+    const long m = i / ns4;
+    const int n = (int)(i - m * ns4) * 4;
+    if (n >= N) continue;
+    f32x4 v = reinterpret_cast<const f32x4*>(partial)[i];
+    for (int z = 1; z < ks; ++z) v += reinterpret_cast<const f32x4*>(partial)[(size_t)z * MN4 + i];
+    v = v * out_scale;
+    for (int e = 0; e < 4 && n + e < N; ++e) {
+      float x = v[e] + bias[n + e];
+      if (act == CF_ACT_RELU) x = fmaxf(x, 0.0f);
+      out[(size_t)m * out_stride + n + e] = x;
+    }
+  }
+}
+
+// number of K parts of a DCN launch on an H x W map (per-image geometry only)
+int dcn_k_split(int H, int W, int n_chunks, int n_pad) {
+  const long hw = (long)H * W;
+  int ks = hw <= 512 ? 4 : (hw <= 2048 && n_pad <= 128) ? 2 : 1;   // (256 outputs at 28x50: the reduction pass costs what the split saves)
+  while (ks > 1 && n_chunks < 4 * ks) ks >>= 1;
+  return ks;
 }
 
 template <typename K, typename A>
@@ -532,12 +584,30 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   CF_REQUIRE(!a->out_split_bf16 || (a->split_stride >= a->N && a->split_stride % 8 == 0 && a->N % 4 == 0),
              "cf_dcn_v2_f16x3: split output needs N %% 4 == 0 and a plane stride >= N that is a multiple of 8");
   hipStream_t st = (hipStream_t)stream;
+  // K split for small maps, when the caller provides the workspace (decided per image geometry, never
+  // by the batch size: it changes the summation order, and a shard has to reproduce the full batch)
+  const unsigned ks = a->workspace ? (unsigned)dcn_k_split(a->H, a->W, k.n_chunks, a->N_pad) : 1u;
+  CF_REQUIRE(ks == 1 || !a->out_split_bf16, "cf_dcn_v2_f16x3: the split-bf16 output is not available on K-split maps");
+  k.partial = static_cast<float*>(a->workspace);
   if (a->N_pad <= 64) {          // 64 channels: 2 x 32-channel wave rows, 2 x 64 pixels
-    launch_f16(dcn_f16x3_kernel<2, 2, 1>, dim3((unsigned)((M + 127) / 128), (unsigned)((a->N_pad + 63) / 64)), 0, st, k);
+    launch_f16(dcn_f16x3_kernel<2, 2, 1>, dim3((unsigned)((M + 127) / 128), (unsigned)((a->N_pad + 63) / 64), ks), 0, st, k);
   } else if (a->N_pad <= 128) {  // 128 channels: 4 x 32-channel wave rows, 64 pixels
-    launch_f16(dcn_f16x3_kernel<4, 1, 1>, dim3((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 127) / 128)), 0, st, k);
+    launch_f16(dcn_f16x3_kernel<4, 1, 1>, dim3((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 127) / 128), ks), 0, st, k);
   } else {
-    launch_f16(dcn_f16x3_kernel<4, 1, 2>, dim3((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 255) / 256)), 0, st, k);
+    launch_f16(dcn_f16x3_kernel<4, 1, 2>, dim3((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 255) / 256), ks), 0, st, k);
+  }
+  if (ks > 1) {
+    const int ns4 = k.n_rt * 32 / 4;
+    const long MN4 = M * ns4;
+    const long blocks = (MN4 + 255) / 256;
+    hipLaunchKernelGGL(dcn_reduce_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, k.partial,
+                       (int)ks, MN4, ns4, a->N, a->bias, a->out_scale, a->act, a->out, a->out_stride);
   }
   return cf_check_launch("cf_dcn_v2_f16x3");
+}
+
+extern "C" size_t cf_dcn_v2_workspace_bytes(int B, int H, int W, int C, int N_pad) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || N_pad <= 0) return 0;
+  const int ks = dcn_k_split(H, W, 9 * C / 32, N_pad);
+  return ks > 1 ? (size_t)ks * B * H * W * N_pad * sizeof(float) : 0;
 }

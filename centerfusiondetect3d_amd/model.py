@@ -237,7 +237,11 @@ class _Plan:
             conv(p + ".conv_offset_mask", [x], h, w, act=ACT_NONE, out=om, out_stride=32)
             pd = pk[p]
             o = buf(B, h, w, pd.n)
-            a = ops.dcn_args(pd, x, om, 32, B, h, w, o, pd.n, ACT_RELU, precise=model.precise)
+            ws = None
+            if pd.out_scale > 0:
+                nbytes = self.lib.cf_dcn_v2_workspace_bytes(B, h, w, pd.c, pd.n_pad)
+                ws = buf(nbytes, dtype=torch.uint8) if nbytes else None
+            a = ops.dcn_args(pd, x, om, 32, B, h, w, o, pd.n, ACT_RELU, precise=model.precise, workspace=ws)
             self.keep.append(a)
             self.step_index[p] = len(self.steps)
             self.step_flops[p] = 2.0 * B * h * w * pd.n * 9 * pd.c
@@ -335,6 +339,7 @@ class _Plan:
                         and a.out_scale > 0 and a.N == 64]
             if producer:
                 producer[-1].out_split_bf16, producer[-1].split_stride = feat_in.data_ptr(), 64
+                producer[-1].workspace = None          # (the split output and a K-split reduction exclude each other)
             else:
                 self.steps.append((self.lib.cf_split_bf16, feat.data_ptr(), feat_in.data_ptr(), M4, 64, 64, 64))
         else:

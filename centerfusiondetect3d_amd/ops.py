@@ -172,7 +172,7 @@ def run_head_tail(a):
 
 
 def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act=ACT_RELU,
-             precise=True, out_split=None):
+             precise=True, out_split=None, workspace=None):
     a = _lib.DcnArgs()
     a.x, a.offmask, a.om_stride = x.data_ptr(), offmask.data_ptr(), om_stride
     a.B, a.H, a.W, a.C = B, H, W, pd.c
@@ -182,6 +182,8 @@ def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act
     a.out_scale = float(getattr(pd, "out_scale", 0.0))
     if out_split is not None:            # (B,H,W,2,Cs) bf16: split copy for the head kernels (f16x3 kernel only)
         a.out_split_bf16, a.split_stride = out_split.data_ptr(), out_split.shape[-1]
+    if workspace is not None:            # K split on small maps (cf_dcn_v2_workspace_bytes)
+        a.workspace = workspace.data_ptr()
     return a
 
 
@@ -190,12 +192,17 @@ def run_dcn(a: _lib.DcnArgs):
     _lib.check(fn(C.byref(a), _lib.stream_ptr()), "cf_dcn_v2")
 
 
-def dcn_v2_fused(pd: PackedDcn, x, offmask, act=ACT_RELU, precise=True):
+def dcn_v2_fused(pd: PackedDcn, x, offmask, act=ACT_RELU, precise=True, k_split=True):
     """x (B,H,W,C) NHWC, offmask (B,H,W,S>=27) NHWC raw conv_offset_mask output."""
     _need_cuda(x, offmask)
     B, H, W, _ = x.shape
     out = torch.empty((B, H, W, pd.n), device=x.device, dtype=torch.float32)
-    run_dcn(dcn_args(pd, x, offmask, offmask.shape[-1], B, H, W, out, pd.n, act, precise))
+    ws = None
+    if k_split and getattr(pd, "out_scale", 0.0) > 0:
+        nbytes = _lib.load().cf_dcn_v2_workspace_bytes(B, H, W, pd.c, pd.n_pad)
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8) if nbytes else None
+    a = dcn_args(pd, x, offmask, offmask.shape[-1], B, H, W, out, pd.n, act, precise, workspace=ws)
+    run_dcn(a)
     return out
 
 

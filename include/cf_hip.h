@@ -200,6 +200,9 @@ typedef struct cf_dcn_args {
   void* out_split_bf16; /* cf_dcn_v2_f16x3 only, optional: the same result additionally as split-bf16 NHWC
                            [B][H][W][2 (hi, lo)][split_stride] - what the head kernels read (saves cf_split_bf16) */
   int32_t split_stride; /* channels per plane of out_split_bf16 (>= N, multiple of 8) */
+  void* workspace;      /* cf_dcn_v2_f16x3 only, optional: cf_dcn_v2_workspace_bytes(...) bytes.  With it, small
+                           maps (<= 2048 pixels per image) split K over 2-4 workgroups per tile and a second
+                           launch adds the partial sums in fixed order; without it K is never split */
 } cf_dcn_args;
 int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream);
 
@@ -207,6 +210,7 @@ int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream);
  * cf_conv2d_f16x3); weight = fragment-packed fp16 hi/lo planes of 2^s * W in (tap, channel) K order
  * (packing.pack_dcn_f16), out_scale = 2^-(s+4).  x / offmask / out stay fp32 NHWC. */
 int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream);
+size_t cf_dcn_v2_workspace_bytes(int B, int H, int W, int C, int N_pad);
 
 /* cf_upsample_dw: depthwise transposed conv (k = 2f, stride f, pad f/2, groups = C, no bias),
  * optionally fused with the IDA skip add:  out = convT(x) [+ skip].

@@ -603,7 +603,10 @@ def test_dcn_v2_f16x3(dev, B, Ci, Co, H, W, mag):
     out2 = torch.empty_like(out)
     a = ops.dcn_args(pd, nhwc(x).to(dev), om32.to(dev), 32, B, H, W, out2, Co, out_split=split)
     ops.run_dcn(a)
-    assert torch.equal(out2, out) and torch.equal(split, ops.split_bf16(out))
+    assert torch.equal(split, ops.split_bf16(out2))
+    # (out used the K-split form on small maps, out2 - no workspace - did not: same value, other summation order)
+    assert float((out2 - out).abs().max()) <= 2e-6 * float(ref.abs().max())
+    assert torch.equal(out2, ops.dcn_v2_fused(pd, nhwc(x).to(dev), om32.to(dev), k_split=False))
 
 
 # ----------------------------------------------------------------------------------- fused stem
