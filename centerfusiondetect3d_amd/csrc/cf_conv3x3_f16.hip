@@ -399,7 +399,10 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
     // layers - with enough tiles to go round, 8 waves (two pixel groups per channel group, 128 pixels)
     // halve that stream (the second group's fragment loads hit L1)
     const long tiles128 = (M + 127) / 128 * ((a->N_pad + 255) / 256);
-    if (cfg(1)) ok = (tiles128 >= 160 && try_launch<4, 2, 1, 2, 2, true, 1>(k, B, st)) || try_launch<4, 1, 1, 2, 4, true, 2>(k, B, st);
+    // smallest maps (level5, 14x25): 128 channels x 64 pixels per workgroup with K split over wave pairs
+    // doubles the workgroup count and halves every wave's round chain (per-image rule, see above)
+    if ((long)a->H * a->W <= 512 && cfg(2)) ok = try_launch<2, 1, 2, 2, 4, true, 2>(k, B, st);
+    if (!ok && cfg(1)) ok = (tiles128 >= 160 && try_launch<4, 2, 1, 2, 2, true, 1>(k, B, st)) || try_launch<4, 1, 1, 2, 4, true, 2>(k, B, st);
   }
   if (!ok) return cf_conv2d_f16x3(a, stream);
   return cf_check_launch("cf_conv3x3_f16x3");
