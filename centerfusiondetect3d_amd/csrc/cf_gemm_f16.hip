@@ -293,10 +293,16 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   }
   __syncthreads();
 
-  f32x4 cv[WP][4][2];   // 4 corners x 8 channels, requested one chunk ahead
-  f32x4 cw[WP];         // corner weights
-  float cmk[WP];        // 16 * sigmoid(mask)
-  auto load_b = [&](int c) {
+  // corner samples are requested TWO chunks ahead (sets c & 1): the texture path, which bounds the
+  // 64-channel layers, then always has a full chunk of requests queued behind the one being blended
+  // (DEEP only for the two-pixel-group configuration: with WP = 1 the second set costs an occupancy
+  //  step or spills and measured slower)
+  constexpr bool DEEP = WP == 2;
+  constexpr int NSET = DEEP ? 2 : 1;
+  f32x4 cvs[NSET][WP][4][2];   // 4 corners x 8 channels
+  f32x4 cws[NSET][WP];         // corner weights
+  float cmks[NSET][WP];        // 16 * sigmoid(mask)
+  auto load_b = [&](int c, f32x4 (&cv)[WP][4][2], f32x4 (&cw)[WP], float (&cmk)[WP]) {
     const int tap = c / p.chunks_per_tap;
     const int c0 = (c - tap * p.chunks_per_tap) * 32 + (tid & 3) * 8;
 #pragma unroll
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
       cv[i][3][1] = *reinterpret_cast<const f32x4*>(a3 + 4);
     }
   };
-  auto store_b = [&](unsigned char* buf) {
+  auto store_b = [&](unsigned char* buf, const f32x4 (&cv)[WP][4][2], const f32x4 (&cw)[WP], const float (&cmk)[WP]) {
 #pragma unroll
     for (int i = 0; i < WP; ++i) {
       const int pr = tid + 256 * i;
@@ -385,27 +391,41 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   // and one tile's chunk chain is latency-bound): this workgroup owns chunks [c_lo, c_hi)
   const int c_lo = (int)((long)p.n_chunks * blockIdx.z / gridDim.z);
   const int c_hi = (int)((long)p.n_chunks * (blockIdx.z + 1) / gridDim.z);
-  load_b(c_lo);
+  // chunk j (relative to c_lo) lives in LDS buffer j & 1 and (DEEP) in register set j & 1
+  const int n_own = c_hi - c_lo;
+  load_b(c_lo, cvs[0], cws[0], cmks[0]);
   load_w(wh[0], wl[0], 2 * c_lo);
   load_w(wh[1], wl[1], 2 * c_lo + 1);
-  store_b(smem);
-  if (c_lo + 1 < c_hi) load_b(c_lo + 1);
+  if (DEEP && n_own > 1) load_b(c_lo + 1, cvs[NSET - 1], cws[NSET - 1], cmks[NSET - 1]);
+  store_b(smem, cvs[0], cws[0], cmks[0]);
+  if (n_own > NSET) load_b(c_lo + NSET, cvs[0], cws[0], cmks[0]);
   __syncthreads();
-  // (no sched_barrier pinning here: it buys nothing in this kernel - the staging VALU work, not the
-  //  prefetch distance, is the bound - and an earlier form with exec-masked corner loads glitched
-  //  with it when launched behind unrelated kernels, see tools/stress_dcn.py)
-  for (int c = c_lo; c < c_hi; ++c) {
-    unsigned char* cur = smem + ((c - c_lo) & 1) * BUF;
-    unsigned char* nxt = smem + ((c - c_lo + 1) & 1) * BUF;
+  // (no sched_barrier pinning here: it buys nothing in this kernel, and an earlier form with
+  //  exec-masked corner loads glitched with it when launched behind unrelated kernels, see
+  //  tools/stress_dcn.py)
+  auto iteration = [&](int j, f32x4 (&cv)[WP][4][2], f32x4 (&cw)[WP], float (&cmk)[WP]) {
+    // MFMAs of chunk j; then chunk j+1 (held in set cv) is blended into the other buffer and the set is
+    // re-requested for chunk j+1+NSET
+    unsigned char* cur = smem + (j & 1) * BUF;
+    unsigned char* nxt = smem + ((j + 1) & 1) * BUF;
+    const int c = c_lo + j;
     mma_kstep(cur, 0, wh[0], wl[0]);
-    if (c + 1 < c_hi) load_w(wh[0], wl[0], 2 * c + 2);
+    if (j + 1 < n_own) load_w(wh[0], wl[0], 2 * c + 2);
     mma_kstep(cur, 1, wh[1], wl[1]);
-    if (c + 1 < c_hi) {
+    if (j + 1 < n_own) {
       load_w(wh[1], wl[1], 2 * c + 3);
-      store_b(nxt);
-      if (c + 2 < c_hi) load_b(c + 2);
+      store_b(nxt, cv, cw, cmk);
+      if (j + 1 + NSET < n_own) load_b(c + 1 + NSET, cv, cw, cmk);
     }
     __syncthreads();
+  };
+  if (DEEP) {
+    for (int j = 0; j < n_own; j += 2) {
+      iteration(j, cvs[NSET - 1], cws[NSET - 1], cmks[NSET - 1]);     // chunk j+1 was requested into set 1
+      if (j + 1 < n_own) iteration(j + 1, cvs[0], cws[0], cmks[0]);
+    }
+  } else {
+    for (int j = 0; j < n_own; ++j) iteration(j, cvs[0], cws[0], cmks[0]);
   }
 
   if (gridDim.z > 1) {   // raw partial sums; scale / bias / activation happen in the reduction
