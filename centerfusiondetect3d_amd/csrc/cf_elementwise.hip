@@ -45,23 +45,22 @@ __global__ __launch_bounds__(256) void upsample_dw_kernel(const float* __restric
   }
 }
 
+// grid = (row segments, output rows, images): one split of the in-row index, no div / mod chain
 __global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                         int B, int H, int W, int C4) {
+                                                         int H, int W, int C4) {
   const int Ho = H / 2, Wo = W / 2;
-  const long total = (long)B * Ho * Wo * C4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    long pix = i / C4;
-    const int xo = (int)(pix % Wo);
-    pix /= Wo;
-    const int yo = (int)(pix % Ho);
-    const int b = (int)(pix / Ho);
-    const f32x4* p = reinterpret_cast<const f32x4*>(x) + ((long)(b * H + 2 * yo) * W + 2 * xo) * C4 + c4;
-    const f32x4 a = p[0], bq = p[C4], c = p[(long)W * C4], d = p[(long)W * C4 + C4];
+  const int yo = blockIdx.y, b = blockIdx.z;
+  const int row_len = Wo * C4;
+  const f32x4* in0 = reinterpret_cast<const f32x4*>(x) + ((size_t)(b * H + 2 * yo) * W) * C4;
+  f32x4* o = reinterpret_cast<f32x4*>(out) + ((size_t)b * Ho + yo) * row_len;
+  for (int j = blockIdx.x * 256 + threadIdx.x; j < row_len; j += gridDim.x * 256) {
+    const int xo = j / C4, c4 = j - xo * C4;
+    const f32x4* p = in0 + (size_t)(2 * xo) * C4 + c4;
+    const f32x4 a = p[0], bq = p[C4], c = p[(size_t)W * C4], d = p[(size_t)W * C4 + C4];
     f32x4 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) r[e] = fmaxf(fmaxf(a[e], bq[e]), fmaxf(c[e], d[e]));
-    reinterpret_cast<f32x4*>(out)[i] = r;
+    o[j] = r;
   }
 }
 
@@ -124,9 +123,10 @@ extern "C" int cf_upsample_dw(const float* x, const float* weight, const float* 
 extern "C" int cf_maxpool2x2(const float* x, float* out, int B, int H, int W, int C, void* stream) {
   CF_REQUIRE(x && out, "cf_maxpool2x2: null buffer");
   CF_REQUIRE(B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "cf_maxpool2x2: bad geometry");
-  const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, out, B, H,
-                     W, C / 4);
+  CF_REQUIRE(H / 2 < 65536 && B < 65536, "cf_maxpool2x2: too many rows / images for the launch grid");
+  const int row_len = (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2x2_kernel, dim3((unsigned)((row_len + 255) / 256), (unsigned)(H / 2), (unsigned)B),
+                     dim3(256), 0, (hipStream_t)stream, x, out, H, W, C / 4);
   return cf_check_launch("cf_maxpool2x2");
 }
 
