@@ -44,6 +44,18 @@ def test_struct_layouts_match_c(tmp_path):
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     assert got == [ctypes.sizeof(_lib.ConvArgs), ctypes.sizeof(_lib.DcnArgs), ctypes.sizeof(_lib.DecodeArgs),
                    16, _lib.ConvArgs.weight.offset, _lib.ConvArgs.precise.offset, _lib.DcnArgs.precise.offset]
+    # the structs added later: stem, head tail / fused head (size and the last field's offset pin the layout)
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cf_hip.h"\nint main(){'
+                    'printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(cf_stem_args), offsetof(cf_stem_args, out),'
+                    'sizeof(cf_head_tail_args), offsetof(cf_head_tail_args, act),'
+                    'sizeof(cf_head_fused_args), offsetof(cf_head_fused_args, w_out_perm),'
+                    'offsetof(cf_dcn_args, workspace), offsetof(cf_dcn_args, out_split_bf16));return 0;}')
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == [ctypes.sizeof(_lib.StemArgs), _lib.StemArgs.out.offset,
+                   ctypes.sizeof(_lib.HeadTailArgs), _lib.HeadTailArgs.act.offset,
+                   ctypes.sizeof(_lib.HeadFusedArgs), _lib.HeadFusedArgs.w_out_perm.offset,
+                   _lib.DcnArgs.workspace.offset, _lib.DcnArgs.out_split_bf16.offset]
 
 
 def test_argument_validation_without_gpu():
