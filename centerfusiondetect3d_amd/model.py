@@ -483,6 +483,43 @@ class _Plan:
         return [y]
 
 
+    # ------------------------------------------------------------------------------ graph replay
+    def replay(self, model, x, pc_dep, calib):
+        """The same launches as run(), captured once into a HIP graph over static input / output
+        buffers and replayed per call (hipGraphLaunch instead of ~90 kernel launches from Python).
+        Semantics are those of run(): fresh output tensors every call (copies out of the static ones),
+        `pc_hm_in` a view of the CALLER's pc_dep, `calib` the caller's tensor."""
+        if getattr(self, "graph", None) is None:
+            self.run(model, x, pc_dep, calib)                       # warm-up: one-time attribute calls, lazy init
+            torch.cuda.synchronize()
+            self.g_x = x.clone()
+            self.g_pc = pc_dep.clone() if pc_dep is not None else None
+            self.g_calib = calib.clone() if calib is not None else None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.g_out = self.run(model, self.g_x, self.g_pc, self.g_calib)[0]
+            self.graph = g
+        self.g_x.copy_(x)
+        if self.g_pc is not None:
+            self.g_pc.copy_(pc_dep)
+        if self.g_calib is not None:
+            self.g_calib.copy_(calib)
+        self.graph.replay()
+        y, fresh = {}, {}
+        for k, v in self.g_out.items():
+            if k == "calib":
+                y[k] = calib
+            elif k == "pc_hm_in":
+                y[k] = pc_dep[:, :1]
+            else:                                                   # aliases in g_out stay aliases (depthMap / pc_hm views)
+                base = v._base if v._base is not None else v
+                if id(base) not in fresh:
+                    fresh[id(base)] = base.clone()
+                nb = fresh[id(base)]
+                y[k] = nb if v._base is None else nb.as_strided(v.size(), v.stride(), v.storage_offset() - base.storage_offset())
+        return [y]
+
+
 # ----------------------------------------------------------------------------------- the module
 class DLASeg(nn.Module):
     def __init__(self, num_layers, in_channels, config):
@@ -515,6 +552,9 @@ class DLASeg(nn.Module):
         self._plans = {}
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
+        self.use_graph = False   # replay the forward as ONE captured HIP graph (inputs / outputs staged through
+                                 # static buffers) instead of ~90 launches from Python.  Measured: no gain - the
+                                 # path is not launch-bound (bs=1: 2.88 ms eager, 2.92 ms replay) - hence off
         self.stem_fused = True   # with conv_f16: base_layer + level0 + level1 in one launch (cf_stem.hip)
         self.conv_patch = True   # 3x3 stride-1 f16x3 convs: LDS patch reuse (cf_conv3x3_f16.hip)
         self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)
@@ -677,6 +717,8 @@ class DLASeg(nn.Module):
         if plan is None:
             plan = self._plans[key] = _Plan(self, B, H, W, dev)
         with torch.cuda.device(dev):
+            if self.use_graph:
+                return plan.replay(self, x, pc_dep, calib)
             return plan.run(self, x, pc_dep, calib)
 
 

@@ -291,3 +291,37 @@ def test_forward_is_reproducible_behind_unrelated_kernels(dev):
             y = m(xd, pc_dep=pd, calib=cd)[0]
             for k in ref:
                 assert torch.equal(y[k], ref[k]), f"forward {i}: {k} differs from the first forward"
+
+
+@pytest.mark.parametrize("radar,B", [(True, 2), (False, 1)])
+def test_graph_replay_equals_eager(dev, radar, B):
+    """model.use_graph: the forward captured once as a HIP graph and replayed - same bits as the eager
+    launches, fresh output tensors per call, `pc_hm_in` still a view of the caller's pc_dep, and new
+    inputs really flow through the static buffers."""
+    H, W = 128, 160
+    m = _model(radar, dev, (H, W))
+    outs = {}
+    for seed in (11, 12):
+        x, pc_dep, calib = cases.model_inputs(B, H, W, seed=seed, radar=radar)
+        xd, pd, cd = x.to(dev), (pc_dep.to(dev) if radar else None), calib.to(dev)
+        with torch.no_grad():
+            m.use_graph = False
+            eager = m(xd, pc_dep=pd, calib=cd)[0]
+            m.use_graph = True
+            graph = m(xd, pc_dep=pd, calib=cd)[0]
+            again = m(xd, pc_dep=pd, calib=cd)[0]
+        assert list(graph.keys()) == list(eager.keys())
+        for k in eager:
+            if k == "calib":
+                assert graph[k].data_ptr() == eager[k].data_ptr() == cd.data_ptr()
+                continue
+            assert torch.equal(graph[k], eager[k]), (seed, k)
+            assert torch.equal(again[k], eager[k]), (seed, k)
+            if k != "pc_hm_in":
+                assert again[k].data_ptr() != graph[k].data_ptr(), k       # fresh tensors every call
+        if radar:
+            assert graph["pc_hm_in"].data_ptr() == pd.data_ptr()
+            assert graph["pc_hm"].data_ptr() == graph["pc_hm_out"].data_ptr()      # aliases stay aliases
+        outs[seed] = eager["heatmap"].clone()
+    assert not torch.equal(outs[11], outs[12])
+    m.use_graph = False
