@@ -8,8 +8,8 @@ element (elements near zero are judged against the map's scale, 2.5x tighter tha
 TWO fp32 evaluations: the DCN neck amplifies rounding ~100x at samples that sit on a cell or image
 border, and against a float64 run of the same network the reference's own fp32 arithmetic is off by
 up to ~1e-4 normwise in the worst of ~10^5..10^6 elements (tools/stage_error.py) - as is this
-implementation, whose RMS error is at or below the fp32 reference's
-(test_accuracy_anchored_on_float64 holds it to that).  The worst normwise error actually observed is
+implementation, whose RMS error equals the fp32 reference's within a few per cent
+(test_accuracy_anchored_on_float64 holds it to 1.25x).  The worst normwise error actually observed is
 printed (pytest -s) and quoted in DESIGN.md."""
 import os
 
