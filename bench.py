@@ -153,6 +153,11 @@ def main():
     ap.add_argument("--height", type=int, default=448)
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="sub-batches of the per-GPU batch on concurrent HIP streams (model.streams).  2 measures "
+                         "+4-5 %% (the other sub-batch fills under-filled launches) but kernels then overlap, so the "
+                         "per-launch roofline timing and the rocprofv3 trace (which serialises streams) stop "
+                         "describing the same thing: the contract line is taken on one stream")
     ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU-oracle sample (bs=4 batches)")
     args = ap.parse_args()
 
@@ -179,6 +184,7 @@ def main():
     assume_equal_shards(True)
     B, H, W = args.batch, args.height, args.width
     model = synthetic_weights(getModel(centerfusion_middle_config((H, W))), seed=0).to(dev).eval()
+    model.streams = max(1, args.streams)
     images, pc_dep, calib = make_inputs(B, H, W, dev, seed=1000 + rank)
 
     def step():

@@ -410,14 +410,16 @@ class _Plan:
                     head_out(h, s1, ss)
 
     # ------------------------------------------------------------------------------------------
-    def run(self, model, x, pc_dep, calib):
+    def run(self, model, x, pc_dep, calib, alloc=None):
+        """alloc(c): where a (B, c, h4, w4) output goes (default: a fresh tensor) - the two-stream
+        forward hands out batch slices of full-batch tensors here."""
         B, H, W, dev = self.B, self.H, self.W, self.device
         lib = self.lib
         st = _lib.stream_ptr()
         h4, w4 = self.h4, self.w4
         heads = model.config.heads
         y = {}
-        new = lambda c: torch.empty((B, c, h4, w4), device=dev, dtype=torch.float32)
+        new = alloc or (lambda c: torch.empty((B, c, h4, w4), device=dev, dtype=torch.float32))
         def set_out(h, t, second=False):
             if h in self.tails:
                 a, n = self.tails[h]
@@ -552,6 +554,8 @@ class DLASeg(nn.Module):
         self._plans = {}
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
+        self.streams = 1         # > 1: the batch as that many sub-batches on concurrent HIP streams (own plans)
+        self._stream_pool = {}
         self.use_graph = False   # replay the forward as ONE captured HIP graph (inputs / outputs staged through
                                  # static buffers) instead of ~90 launches from Python.  Measured: no gain - the
                                  # path is not launch-bound (bs=1: 2.88 ms eager, 2.92 ms replay) - hence off
@@ -712,6 +716,9 @@ class DLASeg(nn.Module):
             calib = calib.reshape(B, 3, 4).float().contiguous()
         if self._packed is None:
             self._prepare(dev)
+        if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 4 and not self.use_graph:
+            with torch.cuda.device(dev):
+                return self._forward_concurrent(x, pc_dep, calib, B, H, W, dev)
         key = (B, H, W, dev)
         plan = self._plans.get(key)
         if plan is None:
@@ -720,6 +727,54 @@ class DLASeg(nn.Module):
             if self.use_graph:
                 return plan.replay(self, x, pc_dep, calib)
             return plan.run(self, x, pc_dep, calib)
+
+    def _forward_concurrent(self, x, pc_dep, calib, B, H, W, dev):
+        """The batch as `self.streams` sub-batches, each with its OWN plan (own intermediate buffers) on
+        its OWN HIP stream: several layers cannot fill the chip on their own (level4: 175 workgroups for
+        256 CUs, the 14x25 / 28x50 maps of the neck, the tail round of most grids) and the other
+        sub-batch's launches fill those holes.  Frames are independent, so the result is the single-stream
+        one bit for bit; outputs are batch slices of full-batch tensors (no concatenation)."""
+        n = self.streams
+        k = B // n
+        h4, w4 = H // 4, W // 4
+        cur = torch.cuda.current_stream(dev)
+        pool = self._stream_pool.setdefault(dev, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(dev))
+        pool = pool[:n]
+        full, ys = [], []
+        for i in range(n):
+            key = (k, H, W, dev, i)
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = self._plans[key] = _Plan(self, k, H, W, dev)
+            count = [0]
+
+            def alloc(c, i=i, count=count):
+                j = count[0]
+                count[0] += 1
+                if i == 0:
+                    full.append(torch.empty((B, c, h4, w4), device=dev, dtype=torch.float32))
+                return full[j][i * k:(i + 1) * k]
+
+            sl = slice(i * k, (i + 1) * k)
+            s = pool[i]
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                ys.append(plan.run(self, x[sl], pc_dep[sl] if pc_dep is not None else None,
+                                   calib[sl] if calib is not None else None, alloc=alloc)[0])
+        for s in pool:
+            cur.wait_stream(s)
+        y = {}
+        for key_, v in ys[0].items():
+            if key_ == "calib":
+                y[key_] = calib
+            elif key_ == "pc_hm_in":
+                y[key_] = pc_dep[:, :1]
+            else:      # a batch slice (or a view of one) of a full tensor -> the same view over the whole batch
+                base = v._base if v._base is not None else v
+                y[key_] = torch.as_strided(base, (B,) + tuple(v.shape[1:]), v.stride(), v.storage_offset())
+        return [y]
 
 
     # ------------------------------------------------------------------------- instrumentation

@@ -325,3 +325,29 @@ def test_graph_replay_equals_eager(dev, radar, B):
         outs[seed] = eager["heatmap"].clone()
     assert not torch.equal(outs[11], outs[12])
     m.use_graph = False
+
+
+def test_two_stream_forward_equals_single_stream(dev):
+    """model.streams = 2: the batch as two sub-batches with their own plans on concurrent HIP streams -
+    bit for bit the single-stream result (also on repetition: no buffer is shared between the streams),
+    full-batch output tensors, views and aliases as in the single-stream dict."""
+    from centerfusiondetect3d_amd import decode_packed
+    H, W, B = 448, 800, 16
+    m = _model(True, dev, (H, W))
+    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=45, radar=True, n_points=(50, 200))
+    xd, pd, cd = x.to(dev), pc_dep.to(dev), calib.to(dev)
+    with torch.no_grad():
+        one = m(xd, pc_dep=pd, calib=cd)
+        det1, _ = decode_packed([dict(one[0])], (112, 200), 100)     # (decode renames rotation2 in the dict it gets)
+        m.streams = 2
+        for rep in range(4):
+            two = m(xd, pc_dep=pd, calib=cd)
+            assert list(two[0].keys()) == list(one[0].keys())
+            for k in one[0]:
+                assert two[0][k].shape == one[0][k].shape, k
+                assert torch.equal(two[0][k], one[0][k]), (rep, k)
+            det2, _ = decode_packed([dict(two[0])], (112, 200), 100)
+            assert torch.equal(det1, det2)
+        assert two[0]["pc_hm_in"].data_ptr() == pd.data_ptr()
+        assert two[0]["pc_hm"].data_ptr() == two[0]["pc_hm_out"].data_ptr()
+        m.streams = 1
