@@ -122,6 +122,21 @@ def main():
         keys = [k for k in y if k != "calib" and y[k] is not None]
         arrays = {f"out_{k}": y[k] for k in keys}
         arrays["key_order"] = np.array(list(y.keys()))
+        # per-stage outputs of the reference's own sub-modules (dla.py:627-635): backbone levels,
+        # DLA-up outputs, the IDA-up feature map - stored as sampled values + a float64 sum each
+        with torch.no_grad():
+            levels = model.base(x)
+            ups = model.dla_up([t.clone() for t in levels])
+            yy = [ups[i].clone() for i in range(3)]
+            model.ida_up(yy, 0, len(yy))
+        for name, t in ([(f"y{i}", t) for i, t in enumerate(levels)] + [(f"up{i}", t) for i, t in enumerate(ups)]
+                        + [("feat", yy[-1])]):
+            flat = t.reshape(-1)
+            idx = sample_idx(flat.numel(), m=2048, seed=321)
+            arrays[f"stage_idx_{name}"] = idx
+            arrays[f"stage_val_{name}"] = flat[idx]
+            arrays[f"stage_sum_{name}"] = np.array(float(flat.double().sum()))
+            arrays[f"stage_shape_{name}"] = np.array(t.shape)
         if radar:
             arrays["n_painted"] = np.array(int((y["pc_hm"] != 0).sum()))
             print("  frustum painted pixels:", int(arrays["n_painted"]))

@@ -351,3 +351,33 @@ def test_two_stream_forward_equals_single_stream(dev):
         assert two[0]["pc_hm_in"].data_ptr() == pd.data_ptr()
         assert two[0]["pc_hm"].data_ptr() == two[0]["pc_hm_out"].data_ptr()
         m.streams = 1
+
+
+@pytest.mark.parametrize("tag,radar,B,H,W", [("centerfusion_small", True, 2, 128, 160),
+                                             ("centernet_small", False, 1, 96, 128)])
+def test_stage_buffers_match_reference_submodules(dev, golden_dir, tag, radar, B, H, W):
+    """The HIP path's intermediate maps (plan.debug, NHWC) against values the REFERENCE's own sub-modules
+    produced (`base` levels 1-5, the DLA-up maps, the feature map; level0 never leaves LDS in the fused stem)."""
+    g = np.load(os.path.join(golden_dir, f"model_{tag}.npz"))
+    m = _model(radar, dev, (H, W))
+    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=1, radar=radar)
+    with torch.no_grad():
+        m(x.to(dev), pc_dep=pc_dep.to(dev) if radar else None, calib=calib.to(dev))
+    plan = list(m._plans.values())[-1]
+    dbg = dict(plan.debug)
+    dbg["feat"] = plan.feat
+    checked = 0
+    for n in (k[len("stage_val_"):] for k in g.files if k.startswith("stage_val_")):
+        if n not in dbg:
+            assert n == "y0"
+            continue
+        t = dbg[n].permute(0, 3, 1, 2).contiguous()
+        assert list(t.shape) == g[f"stage_shape_{n}"].tolist(), n
+        got = t.reshape(-1)[torch.from_numpy(g[f"stage_idx_{n}"]).to(dev)].cpu().numpy()
+        ref = g[f"stage_val_{n}"]
+        scale = float(np.abs(ref).max()) + 1e-12
+        err = np.abs(got - ref)
+        assert (err <= RTOL * np.abs(ref) + ATOL_SCALE * scale).all(), (n, float(err.max() / scale))
+        print(f"[stage] {n:>5s}: max|err|/max|ref| = {err.max() / scale:.2e}")
+        checked += 1
+    assert checked == 10

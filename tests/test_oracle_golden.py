@@ -140,3 +140,40 @@ def test_postprocess_matches_reference(golden_dir, seed):
     if seed == 1:                       # boxes with a non-positive dimension are zeroed
         bad = (g["dimension"] <= 0).any(-1)
         assert bad.any() and not g["bboxes3d"][bad].any()
+
+
+def _oracle_stages(sd, x):
+    """backbone levels, DLA-up outputs and the feature map of the oracle, named like the goldens"""
+    layers = list(model_ref.dla34_base(sd, x))
+    d = {f"y{i}": t for i, t in enumerate(layers)}
+    out = [layers[-1]]
+    for i in range(len(layers) - 2 - 1):
+        model_ref._ida(sd, f"dla_up.ida_{i}", layers, len(layers) - i - 2, len(layers))
+        out.insert(0, layers[-1])
+    for i, t in enumerate(out):
+        d[f"up{i}"] = t
+    y = [out[i].clone() for i in range(3)]
+    model_ref._ida(sd, "ida_up", y, 0, 3)
+    d["feat"] = y[-1]
+    return d
+
+
+@pytest.mark.parametrize("tag,radar,B,H,W", [("centerfusion_small", True, 2, 128, 160),
+                                             ("centernet_small", False, 1, 96, 128)])
+def test_stage_outputs_match_reference_submodules(golden_dir, tag, radar, B, H, W):
+    """Per-stage pin: the reference's own `base`, `dla_up`, `ida_up` outputs (sampled values, float64 sums)
+    against the oracle's stages - levels 0-5, the four DLA-up maps, the 64-channel feature map."""
+    g = _load(golden_dir, f"model_{tag}.npz")
+    sd = cases.tuned_state_dict(radar=radar, seed=0)
+    x, _, _ = cases.model_inputs(B, H, W, seed=1, radar=radar)
+    with torch.no_grad():
+        st = _oracle_stages(sd, x)
+    names = sorted(k[len("stage_val_"):] for k in g.files if k.startswith("stage_val_"))
+    assert names == sorted(st.keys()) and len(names) == 11
+    for n in names:
+        t = st[n]
+        assert list(t.shape) == g[f"stage_shape_{n}"].tolist(), n
+        flat = t.reshape(-1)
+        _close(flat[g[f"stage_idx_{n}"]], g[f"stage_val_{n}"], rtol=1e-4, atol=1e-5 * float(flat.abs().max()))
+        np.testing.assert_allclose(float(flat.double().sum()), float(g[f"stage_sum_{n}"]),
+                                   rtol=1e-5, atol=1e-4 * float(flat.abs().max()) * flat.numel() ** 0.5)
