@@ -158,7 +158,7 @@ def main():
                          "+4-5 %% (the other sub-batch fills under-filled launches) but kernels then overlap, so the "
                          "per-launch roofline timing and the rocprofv3 trace (which serialises streams) stop "
                          "describing the same thing: the contract line is taken on one stream")
-    ap.add_argument("--cpu-frames", type=int, default=12, help="frames of the CPU-oracle sample (bs=4 batches)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle sample (bs=4 batches)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
