@@ -78,6 +78,8 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
   const int y_b = y_l0 - 1, x_b = x_l0 - 1;                  // base region origin
   const int y_i = y_b - 3, x_i = x_b - 3;                    // image patch origin
   const long HW = (long)p.H * p.W;
+  // workgroups whose whole image patch lies inside the image (almost all of them) skip every border test
+  const bool interior = y_i >= 0 && x_i >= 0 && y_i + ST_RI <= p.H && x_i + ST_RI <= p.W;
 
   // ---- P0: image patch -> split fp16 -> LDS (zeros outside the image, channel 3 is zero); every load
   //      of the thread is in flight before the first one is used
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
       const int q = tid + 256 * it;
       const int y = y_i + q / ST_RI, x = x_i + q % ST_RI;
       v[it] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      if (q < ST_RI * ST_RI && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+      if (q < ST_RI * ST_RI && (interior || ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W))) {
         const float* src = p.x + (size_t)b * p.C * HW + (size_t)y * p.W + x;
         v[it][0] = src[0];
         if (p.C > 1) v[it][1] = src[HW];
@@ -112,8 +114,11 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
   for (int ks = 0; ks < 13; ++ks) {
     wb[ks][0] = *sfrag(p.w_base, ks * 2 + 0, lane);
     wb[ks][1] = *sfrag(p.w_base, ks * 2 + 1, lane);
-    const int tap = min(4 * ks + kg, 48);                    // taps 49..51 are padding (zero weights)
-    toff[ks] = ((tap / 7) * ST_RI + tap % 7) * 16;
+    // taps 49..51 are padding (zero weights).  Four compile-time candidates, one select per k group:
+    // no per-lane division chain
+    auto off = [](int tap) { tap = tap < 48 ? tap : 48; return ((tap / 7) * ST_RI + tap % 7) * 16; };
+    const int o01 = kg & 1 ? off(4 * ks + 1) : off(4 * ks + 0), o23 = kg & 1 ? off(4 * ks + 3) : off(4 * ks + 2);
+    toff[ks] = kg & 2 ? o23 : o01;
   }
   const f32x4v bias_b = *reinterpret_cast<const f32x4v*>(p.b_base + 4 * kg);
   __syncthreads();
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int y = y_b + py[u], x = x_b + px[u];
-      const bool inside = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const bool inside = interior || ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W);
       f32x4v v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(acc[u][e] * p.s_base + bias_b[e], 0.0f) : 0.0f;
@@ -168,8 +173,8 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
   for (int ks = 0; ks < 5; ++ks) {
     w0h[ks] = *sfrag(p.w_l0, ks * 2 + 0, lane);
     w0l[ks] = *sfrag(p.w_l0, ks * 2 + 1, lane);
-    const int tap = min(2 * ks + (kg >> 1), 8);
-    t0off[ks] = ((tap / 3) * ST_RB + tap % 3) * ST_ROWB + (kg & 1) * 16;
+    auto off = [](int tap) { tap = tap < 8 ? tap : 8; return ((tap / 3) * ST_RB + tap % 3) * ST_ROWB; };
+    t0off[ks] = (kg & 2 ? off(2 * ks + 1) : off(2 * ks)) + (kg & 1) * 16;
   }
   const f32x4v bias_0 = *reinterpret_cast<const f32x4v*>(p.b_l0 + 4 * kg);
   __syncthreads();
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int y = y_l0 + py[u], x = x_l0 + px[u];
-      const bool inside = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const bool inside = interior || ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W);
       f32x4v v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf((accm[u][e] + accs[u][e]) * p.s_l0 + bias_0[e], 0.0f) : 0.0f;
@@ -230,8 +235,8 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
   for (int ks = 0; ks < 5; ++ks) {
     w1h[ks] = *sfrag(p.w_l1, (rt * 5 + ks) * 2 + 0, lane);
     w1l[ks] = *sfrag(p.w_l1, (rt * 5 + ks) * 2 + 1, lane);
-    const int tap = min(2 * ks + (kg >> 1), 8);
-    t1off[ks] = ((tap / 3) * ST_R0 + tap % 3) * ST_ROWB + (kg & 1) * 16;
+    auto off = [](int tap) { tap = tap < 8 ? tap : 8; return ((tap / 3) * ST_R0 + tap % 3) * ST_ROWB; };
+    t1off[ks] = (kg & 2 ? off(2 * ks + 1) : off(2 * ks)) + (kg & 1) * 16;
   }
   const f32x4v bias_1 = *reinterpret_cast<const f32x4v*>(p.b_l1 + 16 * rt + 4 * kg);
   __syncthreads();
