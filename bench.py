@@ -153,6 +153,9 @@ def main():
     ap.add_argument("--height", type=int, default=448)
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--offset-std", type=float, default=0.01,
+                    help="std of the synthetic conv_offset_mask weights: 0.01 -> offsets O(1-3 px) (C2); 0.04 -> O(8 px), "
+                         "BASELINE config C4 (stresses the bilinear gather)")
     ap.add_argument("--streams", type=int, default=1,
                     help="sub-batches of the per-GPU batch on concurrent HIP streams (model.streams).  2 measures "
                          "+4-5 %% (the other sub-batch fills under-filled launches) but kernels then overlap, so the "
@@ -183,7 +186,7 @@ def main():
     from centerfusiondetect3d_amd.distributed import gather_detections, assume_equal_shards
     assume_equal_shards(True)
     B, H, W = args.batch, args.height, args.width
-    model = synthetic_weights(getModel(centerfusion_middle_config((H, W))), seed=0).to(dev).eval()
+    model = synthetic_weights(getModel(centerfusion_middle_config((H, W))), seed=0, offset_std=args.offset_std).to(dev).eval()
     model.streams = max(1, args.streams)
     images, pc_dep, calib = make_inputs(B, H, W, dev, seed=1000 + rank)
 
