@@ -1,8 +1,10 @@
 """Oracle: radar pillar expansion (radar points -> pc_dep map), numpy fp64.
 
-TEST INFRASTRUCTURE - see oracle/__init__.py.  PARITY UNPINNED: the reference module
-(dataset/generic_dataset.py) cannot be imported here (cv2 / pycocotools / lightning at module
-top), so this follows the source text of
+TEST INFRASTRUCTURE - see oracle/__init__.py.  PINNED by golden vectors generated from the
+reference's own Python (tests/golden/make_golden_dataset.py runs `processPointCloud` /
+`getPcPillarsSize` / `drawPcHeat` of the imported reference on real `nuScenes` instances;
+tests/test_oracle_dataset_golden.py compares this restatement with tests/golden/pillar_*.npz
+bit for bit: kept points, pillar sizes, painted maps).  It follows
 
   * /root/reference/src/lib/dataset/generic_dataset.py:738-828   processPointCloud
   * generic_dataset.py:830-867                                   transformPointCloud
@@ -12,8 +14,11 @@ top), so this follows the source text of
   * pointcloud.py:239-296 (numpy branch), utils/ddd.py:8-55      get3DCorners / get3dBox / project3DPoints
   * /root/reference/src/lib/utils/image.py:43-83                 getAffineTransform (rotation 0)
 
-and is held by hand-computable cases and property tests (tests/test_oracle_pillar.py).
-cv2.transform on float64 (2x3 matrix) is restated as  m0*x + m1*y + m2  in fp64.
+Outside the pin (third-party arithmetic absent from /root/reference and the image, served by
+stand-ins while the fixtures were generated): cv2.transform on float64 (restated as
+m0*x + m1*y + m2 in fp64, OpenCV's `transform_<double>` order) and cv2.getAffineTransform (3-point
+solve) - the fixtures carry the resulting 2x3 matrix as an INPUT.  Hand-computable cases and
+property tests: tests/test_oracle_pillar.py.
 """
 import numpy as np
 
@@ -74,9 +79,11 @@ def pillar_wh(pc_3d, calib, trans_out, pillar_dims=(1.5, 0.2, 0.2)):
     zc = np.full(8, 0.5, np.float32); zc[1:3] *= -1; zc[5:7] *= -1; zc *= w
     corners = np.stack([xc, yc, zc], axis=1).astype(np.float64)           # (8,3)
     pts = corners[None, :, :] + pc_3d[:3, :].T.astype(np.float64)[:, None, :]   # (N,8,3)
-    homo = np.concatenate([pts, np.ones((N, 8, 1))], axis=2)              # (N,8,4)
-    calib = np.asarray(calib, np.float64).reshape(3, 4)
-    p2 = np.einsum("ij,nkj->nki", calib, homo)
+    c = np.asarray(calib, np.float64).reshape(3, 4)
+    X, Y, Z = pts[..., 0], pts[..., 1], pts[..., 2]
+    # project3DPoints: the reference's einsum sums the four products of a row left to right,
+    # each rounded (pinned: pillar_kitti.npz has a non-zero fourth calib column)
+    p2 = np.stack([((c[i, 0] * X + c[i, 1] * Y) + c[i, 2] * Z) + c[i, 3] * 1.0 for i in range(3)], axis=-1)
     uv = p2[..., :2] / p2[..., 2:]
     out = transform_points(uv.reshape(-1, 2).T, trans_out).T.reshape(N, 8, 2)
     return np.stack([out[..., 0].max(1) - out[..., 0].min(1),

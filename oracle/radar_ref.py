@@ -10,13 +10,19 @@ on-disk sweep and `processPointCloud`:
       -> keep depth > 0 and 1 < u < width - 1 and 1 < v < height - 1
       -> order by depth (ascending; the training loader reverses it unless PC_REVERSE)
 
-PARITY UNPINNED: `view_points` lives in nuscenes-devkit, a third-party dependency that is absent from
-/root/reference and from this image (requirements.txt: `nuscenes-devkit`, unversioned); it is the
-documented homogeneous product `viewpad @ [p; 1]` followed by the division.  Two things the reference
-leaves to its libraries are fixed here, and the HIP kernel follows the same choices:
+PINNED (all but the last bit of u, v) by golden vectors generated from the reference's own Python:
+tests/golden/make_golden_dataset.py runs `nuScenes.loadRadarPointCloud` of the imported reference on
+pickled sweeps (tests/golden/radar_*.npz; tests/test_oracle_dataset_golden.py): kept set, order, pc_3d
+rows and the painted pc_dep map are bit-exact, u and v agree to 1e-12 relative.  Outside the pin:
+`view_points` lives in nuscenes-devkit, a third-party dependency that is absent from /root/reference and
+from this image (requirements.txt: `nuscenes-devkit`, unversioned); while the fixtures were generated it
+was served by a stand-in with the devkit's documented body (4x4 viewpad @ [p; 1] by np.dot, divided by
+row 2).  Two things the reference leaves to its libraries are fixed here, and the HIP kernel follows
+the same choices:
   * the order of the three products of a projected coordinate - left to right, each rounded
-    (K0*x + K1*y + K2*z; numpy hands the 3x3 @ 3xN product to BLAS, whose summation order / FMA use is
-    not specified, so the last bit of u, v is not defined by the reference itself);
+    (K0*x + K1*y + K2*z; numpy hands the product to BLAS, whose summation order / FMA use is
+    not specified, so the last bit of u, v is not defined by the reference itself - the fixtures show
+    exactly that 1-ulp difference against this build's BLAS);
   * ties in depth - `np.argsort` (quicksort) does not define their order; here the original index breaks
     them (a stable sort), and the descending order is the exact reverse of the ascending one, as
     `index[::-1]` makes it.
