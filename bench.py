@@ -7,7 +7,8 @@
 
 One step = one pass of the hot path over one batch: images / pc_dep / calib already resident in HBM
 -> DLA-34 + DCNv2 neck + primary heads + frustum association + secondary heads (model.forward) ->
-NMS/top-k decode -> (N>1) RCCL all-gather of the (B,100,33) detections.  Workload = BASELINE
+NMS/top-k decode + 2D->3D postProcess (one gather launch) -> (N>1) RCCL all-gather of the final
+(B,100,54) boxes, issued asynchronously so it overlaps the next step's backbone.  Workload = BASELINE
 configs[1]: Centerfusion_Middle, bs=16 per GPU, 3x448x800, <=200-point synthetic radar sweeps,
 random-init weights (no network for checkpoints).  Weak scaling: every rank runs its own 16 frames.
 
@@ -117,31 +118,93 @@ def cpu_threads():
     return min(n, int(os.environ.get("CF_CPU_THREADS", "16")))
 
 
-def cpu_baseline(H, W, frames=2, seed=0):
-    """CPU oracle (our torch-fp32 restatement, kind 'port') forward+decode on `frames` frames."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(H, W, batch=16, runs=3, seed=0):
+    """CPU oracle (our torch-fp32 restatement, kind 'port') per SURVEY.md §8(d): forward + decode timed on this
+    host with all granted cores - C2 (Centerfusion_Middle) at bs=`batch` and bs=1 and C1 (CenterNet) at bs=1,
+    median of `runs` after one warm-up.  `value` = the C2 bs=`batch` rate (the configuration `value` of the
+    contract line is quoted on); the other legs are listed under `runs`.  ~35 s of CPU work at the defaults."""
     from oracle import model_ref, decode_ref
-    sd = model_ref.make_state_dict(radar=True, seed=seed)
     rs = np.random.RandomState(seed)
-    x = torch.from_numpy(rs.standard_normal((frames, 3, H, W)).astype(np.float32))
-    pc_dep = torch.zeros(frames, 3, H // 4, W // 4)
-    for b in range(frames):
-        for d in np.sort(rs.uniform(2, 58, 120)):
-            cx, cy = rs.randint(0, W // 4), rs.randint(2, H // 4)
-            pc_dep[b, 0, max(cy - 12, 0):cy, cx:cx + 2] = float(d)
-    calib = torch.tensor([[1266.4, 0, 816.3, 0], [0, 1266.4, 491.5, 0], [0, 0, 1, 0]]).repeat(frames, 1, 1)
     cores = cpu_threads()
     torch.set_num_threads(cores)
-    bs = 4
+    calib1 = torch.tensor([[1266.4, 0, 816.3, 0], [0, 1266.4, 491.5, 0], [0, 0, 1, 0]])
+
+    def leg(radar, bs):
+        sd = model_ref.make_state_dict(radar=radar, seed=seed)
+        x = torch.from_numpy(rs.standard_normal((bs, 3, H, W)).astype(np.float32))
+        pc_dep = None
+        if radar:
+            pc_dep = torch.zeros(bs, 3, H // 4, W // 4)
+            for b in range(bs):
+                for d in np.sort(rs.uniform(2, 58, 120)):
+                    cx, cy = rs.randint(0, W // 4), rs.randint(2, H // 4)
+                    pc_dep[b, 0, max(cy - 12, 0):cy, cx:cx + 2] = float(d)
+        calib = calib1.repeat(bs, 1, 1)
+        ts = []
+        with torch.no_grad():
+            model_ref.forward(sd, x[:1], pc_dep=pc_dep[:1] if radar else None, calib=calib[:1], radar=radar)   # warm-up
+            for _ in range(runs):
+                t0 = time.perf_counter()
+                y = model_ref.forward(sd, x, pc_dep=pc_dep, calib=calib, radar=radar)
+                decode_ref.fusion_decode(y, (H // 4, W // 4), 100)
+                ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        return {"config": "C2 Centerfusion_Middle" if radar else "C1 CenterNet", "batch": bs,
+                "median_s": round(med, 3), "frames_per_s": round(bs / med, 4)}
+
+    legs = [leg(True, batch), leg(True, 1), leg(False, 1)]
+    total = sum(l["median_s"] for l in legs) * runs
+    return {"value": legs[0]["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
+            "cpu": cpu_model_name(),
+            "sample": f"torch-fp32 oracle forward+decode, 3x{H}x{W}: C2 bs={batch} (the value), C2 bs=1, C1 bs=1; "
+                      f"median of {runs} runs each after a 1-frame warm-up, ~{total:.0f} s of CPU work",
+            "runs": legs}
+
+
+def end_to_end(args, dev, model):
+    """`Detector.run`-shaped line (kept apart from the contract line): uint8 1600x900 camera frames and raw radar
+    sweeps start in pinned HOST memory; per step they cross PCIe, are warped / normalised, ingested and
+    pillar-expanded on the device, go through the model and come out as final 3D boxes (B,100,54)."""
+    from centerfusiondetect3d_amd import Detector
+    from tests.golden import cases_dataset as cd
+    B, H, W = args.batch, args.height, args.width
+    rs = np.random.RandomState(5)
+    frames = torch.from_numpy(rs.randint(0, 256, (B, 900, 1600, 3)).astype(np.uint8)).pin_memory()
+    calib = np.concatenate([cd.NUSC_K, np.zeros((3, 1))], axis=1)
+    infos = [dict(calib=calib.tolist(), camera_intrinsic=cd.NUSC_K.tolist(), width=1600, height=900)] * B
+    sweeps = [cd._sweep(np.random.RandomState(100 + b), int(rs.randint(50, 201))) for b in range(B)]
+    det = Detector(model.config, model=model, device=dev)
+
+    def step():
+        return det.run(frames, infos, sweeps, merge=False)["post"]
+
     with torch.no_grad():
-        model_ref.forward(sd, x[:1], pc_dep=pc_dep[:1], calib=calib[:1])       # warm-up
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(0, frames, bs):
-            y = model_ref.forward(sd, x[i:i + bs], pc_dep=pc_dep[i:i + bs], calib=calib[i:i + bs])
-            decode_ref.fusion_decode(y, (H // 4, W // 4), 100)
+        for _ in range(args.steps):
+            post = step()
+        torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{frames} frames 3x{H}x{W} (bs={bs} forward+decode batches of the torch-fp32 "
-                      f"oracle after a 1-frame warm-up, {dt:.1f} s)"}
+    assert post.shape == (B, 100, 54) and bool(torch.isfinite(post).all())
+    return {"metric": "frames/sec/GPU CenterFusion end-to-end: uint8 1600x900 frames + raw radar sweeps in pinned host "
+                      "memory -> PCIe -> pre-process + radar ingest + pillar expansion -> forward -> decode + postProcess "
+                      "(final 3D boxes on the device)",
+            "value": round(B * args.steps / dt, 2), "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "data": "synthetic", "config": {"workload": f"Detector.run chain, bs={B}, 3x{H}x{W} network input",
+                                            "pcie_bytes_per_frame": 900 * 1600 * 3}}
 
 
 def main():
@@ -161,7 +224,11 @@ def main():
                          "+4-5 %% (the other sub-batch fills under-filled launches) but kernels then overlap, so the "
                          "per-launch roofline timing and the rocprofv3 trace (which serialises streams) stop "
                          "describing the same thing: the contract line is taken on one stream")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the CPU-oracle sample (bs=4 batches)")
+    ap.add_argument("--exact-fp32", action="store_true",
+                    help="every product in exact fp32 (fp32 MFMA kernels with two-level summation; conv_f16 / heads_bf16 "
+                         "off) instead of the default split-operand products - the accuracy reference build, 3.5x slower")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="print the Detector.run-shaped line instead (uint8 frames + raw radar over PCIe -> final boxes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,20 +249,41 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from centerfusiondetect3d_amd import getModel, centerfusion_middle_config, decode_packed
-    from centerfusiondetect3d_amd.distributed import gather_detections, assume_equal_shards
+    from centerfusiondetect3d_amd import getModel, centerfusion_middle_config, decode_post_packed
+    from centerfusiondetect3d_amd.distributed import DetectionGatherer, assume_equal_shards
+    from centerfusiondetect3d_amd.postprocess import inverse_affine_device
     assume_equal_shards(True)
     B, H, W = args.batch, args.height, args.width
-    model = synthetic_weights(getModel(centerfusion_middle_config((H, W))), seed=0, offset_std=args.offset_std).to(dev).eval()
+    model = getModel(centerfusion_middle_config((H, W)))
+    if args.exact_fp32:
+        model.conv_f16 = False
+        model.heads_bf16 = False
+    model = synthetic_weights(model, seed=0, offset_std=args.offset_std).to(dev).eval()
     model.streams = max(1, args.streams)
+    if args.end_to_end:
+        if rank == 0:
+            print(json.dumps(end_to_end(args, dev, model)), flush=True)
+        return
     images, pc_dep, calib = make_inputs(B, H, W, dev, seed=1000 + rank)
+    tinv = inverse_affine_device(np.array([800.0, 450.0], np.float32), 1600.0, (W // 4, H // 4), dev)
+    gatherer = DetectionGatherer(dev)
+    pending = []
 
     def step():
+        """forward -> decode + postProcess -> (N>1) async all-gather of the final boxes; the gather of step i is
+        waited for after step i+1 has been enqueued, so it runs beside that step's backbone."""
         out = model(images, pc_dep=pc_dep, calib=calib)
-        det, _ = decode_packed(out, (H // 4, W // 4), 100)
-        if world > 1:
-            det = gather_detections(det)
-        return det
+        post = decode_post_packed(out, calib, tinv, (H // 4, W // 4), 100)
+        pending.append(gatherer.submit(post))
+        if len(pending) > 1:
+            return pending.pop(0).wait()
+        return None
+
+    def drain():
+        last = None
+        while pending:
+            last = pending.pop(0).wait()
+        return last
 
     def fence():
         torch.cuda.synchronize()
@@ -203,24 +291,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # exact-fp32 build: the heads are unfused fp32-MFMA convolutions; its dominant launches are the two first layers
+    dominant = ["heads.primary.0", "heads.secondary.0"] if args.exact_fp32 else DOMINANT
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
-        for name in DOMINANT:
+        drain()
+        for name in dominant:
             model.time_launch(name, True)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            det = step()
+            step()
+        det = drain()                      # every gather of the timed steps completes inside the timed region
         fence()
         dt = time.perf_counter() - t0
     launch_ms, launch_flops = [], 0.0
-    for name in DOMINANT:
+    for name in dominant:
         ms, fl = model.launch_times(name)
         model.time_launch(name, False)
         launch_ms += ms
         launch_flops += fl * len(ms)
-    assert det.shape == (B * world, 100, 33) and bool(torch.isfinite(det).all())
+    assert det.shape == (B * world, 100, 54) and bool(torch.isfinite(det).all())
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -232,28 +324,34 @@ def main():
         avg_ms = float(np.mean(launch_ms))
         launch_flops = launch_flops / len(launch_ms)          # algorithmic FLOPs of an average launch
         achieved = launch_flops / (avg_ms * 1e-3) / 1e12
+        peak = FP32_MFMA_PEAK_TFLOPS if args.exact_fp32 else BF16_MFMA_PEAK_TFLOPS
         result = {
             "metric": METRIC, "value": round(fps, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("f32" if args.exact_fp32 else
+                      "f32 storage + f32 accumulate; products as 3 split-operand MFMA passes (f16x3 backbone/neck, bf16x3 heads)"),
             "data": "synthetic",
             "config": {"workload": f"Centerfusion_Middle (DLA-34 + DCNv2 neck + pc_dep frustum fusion, 7+4 heads) "
-                                   f"forward + NMS/top-100 decode, bs={B}/GPU, 3x{H}x{W}, 50-200 radar pts/frame, "
+                                   f"forward + NMS/top-100 decode + 2D->3D postProcess, bs={B}/GPU, 3x{H}x{W}, 50-200 radar pts/frame, "
                                    f"random-init weights",
-                       "global_batch": B * world, "parallelism": f"dp{world} (batch shard, all-gather of detections)"},
+                       "global_batch": B * world, "parallelism": f"dp{world} (batch shard, async all-gather of the final boxes)"},
             "per_gpu_frames_per_s": round(fps / world, 2),
             "model_tflops": round(fps * GFLOP_PER_FRAME * (H * W) / (448 * 800) / 1e3, 2),
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": measured_traffic(),
-                         "kernel": "head_patch_kernel (cf_head_fused; 2 launches/step: 7 primary heads, 4 secondary heads)",
-                         "note": "algorithmic FLOPs (2*MACs); the kernel issues 3 bf16 MFMA passes per MAC "
-                                 "(split operands), so MFMA-pipe utilisation is 3x frac",
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                         "traffic": None if args.exact_fp32 else measured_traffic(),
+                         "kernel": ("conv_igemm_kernel (fp32 MFMA; the 3x3 first layers of the 7 primary / 4 secondary heads)"
+                                    if args.exact_fp32 else
+                                    "head_patch_kernel (cf_head_fused; 2 launches/step: 7 primary heads, 4 secondary heads)"),
+                         "note": ("algorithmic FLOPs (2*MACs) against the fp32 MFMA peak" if args.exact_fp32 else
+                                  "algorithmic FLOPs (2*MACs); the kernel issues 3 bf16 MFMA passes per MAC "
+                                  "(split operands), so MFMA-pipe utilisation is 3x frac"),
                          "flop_per_launch": launch_flops, "avg_launch_ms": round(avg_ms, 4),
                          "launches_timed": len(launch_ms)},
         }
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(H, W, frames=args.cpu_frames)
+            result["cpu_baseline"] = cpu_baseline(H, W, batch=B)
         elif world == 1:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)

@@ -65,6 +65,13 @@ class DecodeArgs(C.Structure):
                 ("out_h", C.c_int32), ("out_w", C.c_int32), ("norm2d", C.c_int32), ("det", _f)]
 
 
+class SerializeArgs(C.Structure):
+    _fields_ = [("post", _f), ("B", C.c_int32), ("K", C.c_int32), ("trans_matrix", _f),
+                ("velocity_matrix", _f), ("cs_rot", _f), ("pose_rot", _f), ("rows", _f), ("rotation", _f),
+                ("n_samples", C.c_int32), ("sample_ptr", _f), ("sample_frames", _f),
+                ("max_per_sample", C.c_int32), ("order", _f), ("counts", _f)]
+
+
 # every symbol include/cf_hip.h declares: (restype, argtypes)
 _i, _d = C.c_int, C.c_double
 SYMBOLS = {
@@ -93,6 +100,9 @@ SYMBOLS = {
     "cf_pillar_expand": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _i, _i, _d, _d, _d, _f, _f, _f, _f]),
     "cf_decode_gather": (_i, [C.POINTER(DecodeArgs), _f]),
     "cf_post_process": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _f]),
+    "cf_decode_post": (_i, [C.POINTER(DecodeArgs), _f, _f, _f, _f]),
+    "cf_serialize_nuscenes": (_i, [C.POINTER(SerializeArgs), _f]),
+    "cf_serialize_max_candidates": (_i, []),
     "cf_last_error": (C.c_char_p, []),
     "cf_abi_version": (_i, []),
 }

@@ -5,6 +5,7 @@
 
 The .so is git-ignored but travels to the GPU box with the gpurun snapshot.
 """
+import glob
 import os
 import shutil
 import subprocess
@@ -49,7 +50,8 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(ROOT, "include", "cf_hip.h"), os.path.join(CSRC, "cf_common.h"), __file__]
+    # every header any source may include: editing one rebuilds everything that could depend on it
+    headers = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(CSRC, "*.h"))) + [__file__]
     objs = []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)

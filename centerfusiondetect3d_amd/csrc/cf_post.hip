@@ -404,14 +404,11 @@ __global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
 // ---------------------------------------------------------------------------------------------
 // Detection gather (model/decode.py:40-41, 60-64, 132-172)
 // ---------------------------------------------------------------------------------------------
-__global__ void decode_gather_kernel(cf_decode_args a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.B * a.K) return;
+__device__ __forceinline__ void decode_row(const cf_decode_args& a, int t, float* o) {
   const int b = t / a.K;
   const int HW = a.H * a.W;
   const int pix = a.inds[t];
   const int yi = pix / a.W, xi = pix - yi * a.W;
-  float* o = a.det + (size_t)t * 33;
   const float xn = (float)xi / (float)a.W, yn = (float)yi / (float)a.H;
   o[0] = a.scores[t];
   o[1] = (float)a.classes[t];
@@ -453,20 +450,20 @@ __global__ void decode_gather_kernel(cf_decode_args a) {
   gather(a.depth, 1, 32, 1.0f, 1.0f);
 }
 
+__global__ void decode_gather_kernel(cf_decode_args a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.B * a.K) return;
+  decode_row(a, t, a.det + (size_t)t * 33);
+}
+
 // ---------------------------------------------------------------------------------------------
 // 2D -> 3D post-processing of decoded detections (utils/postProcess.py:13-85), one thread per row.
 // in : det (B,K,33) [score, cls, cxn, cyn, x1, y1, x2, y2, rot8, dim3, amodal2, att8, vel3, depth]
 // out: (B,K,54) [score, cls+1, cx, cy, x1, y1, x2, y2, depth, alpha, dim3, amodal2, att8, vel3,
 //                loc3, yaw, box3d 8x3]
 // ---------------------------------------------------------------------------------------------
-__global__ void post_process_kernel(const float* __restrict__ det, const float* __restrict__ calib,
-                                    const float* __restrict__ tinv, int B, int K, float out_w, float out_h,
-                                    float* __restrict__ out) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= B * K) return;
-  const float* d = det + (size_t)t * 33;
-  const float* cal = calib + (size_t)(t / K) * 12;
-  float* o = out + (size_t)t * 54;
+__device__ __forceinline__ void post_row(const float* d, const float* __restrict__ cal,
+                                         const float* __restrict__ tinv, float out_w, float out_h, float* o) {
   const float t00 = tinv[0], t01 = tinv[1], t02 = tinv[2], t10 = tinv[3], t11 = tinv[4], t12 = tinv[5];
   auto ax = [&](float x, float y) { return (t00 * x + t01 * y) + t02; };
   auto ay = [&](float x, float y) { return (t10 * x + t11 * y) + t12; };
@@ -519,6 +516,169 @@ __global__ void post_process_kernel(const float* __restrict__ det, const float* 
     o[30 + q * 3 + 1] = bad ? 0.0f : by;
     o[30 + q * 3 + 2] = bad ? 0.0f : bz;
   }
+}
+
+__global__ void post_process_kernel(const float* __restrict__ det, const float* __restrict__ calib,
+                                    const float* __restrict__ tinv, int B, int K, float out_w, float out_h,
+                                    float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * K) return;
+  post_row(det + (size_t)t * 33, calib + (size_t)(t / K) * 12, tinv, out_w, out_h, out + (size_t)t * 54);
+}
+
+// decode + postProcess in ONE launch: the 33-float row stays in registers between the two steps
+// (model/decode.py:10-174 -> utils/postProcess.py:13-85); `a.det` may be NULL when only the final rows
+// are wanted.  Same arithmetic as the two kernels above (this file is built without FMA contraction),
+// so the fused rows equal cf_decode_gather + cf_post_process bit for bit.
+__global__ void decode_post_kernel(cf_decode_args a, const float* __restrict__ calib,
+                                   const float* __restrict__ tinv, float* __restrict__ post) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.B * a.K) return;
+  float d[33];
+  decode_row(a, t, d);
+  if (a.det) {
+    float* o = a.det + (size_t)t * 33;
+#pragma unroll
+    for (int i = 0; i < 33; ++i) o[i] = d[i];
+  }
+  post_row(d, calib + (size_t)(t / a.K) * 12, tinv, (float)a.out_w, (float)a.out_h, post + (size_t)t * 54);
+}
+
+// ---------------------------------------------------------------------------------------------
+// nuScenes result serialisation (dataset/datasets/nuscenes.py:416-557)
+// rows (B*K, 12) f32: [translation xyz (global), size w l h, velocity xy (global), score,
+//                      class index 0..9, attribute id 0..8, keep]
+// rotation (B*K, 4) f64: pose * cs * R_y(yaw)   (w, x, y, z)
+// One thread per detection.  fp32 products of the 4x4 transforms are summed pairwise
+// ((p0 + p1) + (p2 + p3)), each operation rounded - the order oracle/serialize_ref.py pins.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot4_pairwise(const float* m, float x, float y, float z, float w) {
+  return (m[0] * x + m[1] * y) + (m[2] * z + m[3] * w);
+}
+
+__device__ __forceinline__ void quat_mul(const double* a, const double* b, double* o) {
+  o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+
+__global__ void serialize_rows_kernel(const float* __restrict__ post, int B, int K,
+                                      const float* __restrict__ trans_matrix,
+                                      const float* __restrict__ velocity_matrix,
+                                      const double* __restrict__ cs_rot, const double* __restrict__ pose_rot,
+                                      float* __restrict__ rows, double* __restrict__ rotation) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * K) return;
+  const int b = t / K;
+  const float* p = post + (size_t)t * 54;
+  const float* tm = trans_matrix + (size_t)b * 16;
+  const float* vm = velocity_matrix + (size_t)b * 16;
+  float* o = rows + (size_t)t * 12;
+  const float score = p[0];
+  const int cls = (int)p[1] - 1;                          // classIds were shifted to 1..10 by postProcess
+  const float dh = p[10], dw = p[11], dl = p[12];
+  // size = dimension[[1, 2, 0]] = (w, l, h); location.y -= h in Python floats (fp64), then fp32
+  const float lx = p[26], lz = p[28];
+  const float ly = (float)((double)p[27] - (double)dh);
+  o[0] = dot4_pairwise(tm + 0, lx, ly, lz, 1.0f);
+  o[1] = dot4_pairwise(tm + 4, lx, ly, lz, 1.0f);
+  o[2] = dot4_pairwise(tm + 8, lx, ly, lz, 1.0f);
+  o[3] = dw; o[4] = dl; o[5] = dh;
+  o[6] = dot4_pairwise(vm + 0, p[23], p[24], p[25], 0.0f);
+  o[7] = dot4_pairwise(vm + 4, p[23], p[24], p[25], 0.0f);
+  o[8] = score;
+  o[9] = (float)cls;
+  // attribute: argmax (first maximum) over the class group's slice of nuscenes_att (nuscenes.py:446-454)
+  const float* att = p + 15;
+  int attr = 0;
+  if (cls == 6 || cls == 7) {                             // motorcycle, bicycle
+    attr = (att[1] > att[0] ? 1 : 0) + 1;
+  } else if (cls == 5) {                                  // pedestrian
+    int m = 2;
+    if (att[3] > att[m]) m = 3;
+    if (att[4] > att[m]) m = 4;
+    attr = (m - 2) + 3;
+  } else if (cls >= 0 && cls <= 4) {                      // car, truck, bus, trailer, construction_vehicle
+    int m = 5;
+    if (att[6] > att[m]) m = 6;
+    if (att[7] > att[m]) m = 7;
+    attr = (m - 5) + 6;
+  }
+  o[10] = (float)attr;
+  // merge filter of model/progressBar.py:116 / detector.py:437: score > -1 and every dimension > 0
+  o[11] = (score > -1.0f && dh > 0.0f && dw > 0.0f && dl > 0.0f) ? 1.0f : 0.0f;
+  if (rotation) {
+    double* q = rotation + (size_t)t * 4;
+    const double half = (double)p[29] / 2.0;
+    const double ry[4] = {cos(half), 0.0, sin(half), 0.0};
+    double tmp[4];
+    if (cs_rot && pose_rot) {
+      quat_mul(cs_rot + (size_t)b * 4, ry, tmp);
+      quat_mul(pose_rot + (size_t)b * 4, tmp, q);
+    } else {
+      q[0] = ry[0]; q[1] = ry[1]; q[2] = ry[2]; q[3] = ry[3];
+    }
+  }
+}
+
+// Per-sample merge of the cameras' results + top-N cut (convert_eval_format, nuscenes.py:536-553):
+// candidates = kept rows of the sample's frames in (frame order, row order); order = stable sort on
+// the score, descending (Python sorts (-score, position)); the best `max_keep` survive.
+// One workgroup per sample; rank by counting over the candidate list in LDS.
+constexpr int SR_THREADS = 256;
+constexpr int SR_MAXC = 6144;   // candidates per sample (6 cameras x K <= 1024)
+
+__global__ __launch_bounds__(SR_THREADS) void serialize_topn_kernel(
+    const float* __restrict__ rows, int K, const int32_t* __restrict__ sample_ptr,
+    const int32_t* __restrict__ sample_frames, int max_keep, int32_t* __restrict__ order,
+    int32_t* __restrict__ counts) {
+  __shared__ float s_score[SR_MAXC];
+  __shared__ int s_row[SR_MAXC];
+  __shared__ int s_wave[SR_THREADS / 64];
+  __shared__ int s_base;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f0 = sample_ptr[s], f1 = sample_ptr[s + 1];
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int f = f0; f < f1; ++f) {
+    const int b = sample_frames[f];
+    for (int j0 = 0; j0 < K; j0 += SR_THREADS) {
+      const int j = j0 + tid;
+      const int row = b * K + j;
+      const bool keep = j < K && rows[(size_t)row * 12 + 11] != 0.0f;
+      const unsigned long long bal = __ballot(keep);
+      if (lane == 0) s_wave[wave] = __popcll(bal);
+      __syncthreads();
+      int off = s_base;
+      for (int w = 0; w < wave; ++w) off += s_wave[w];
+      const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+      if (keep && pos < SR_MAXC) {
+        s_score[pos] = rows[(size_t)row * 12 + 8];
+        s_row[pos] = row;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < SR_THREADS / 64; ++w) tot += s_wave[w];
+        s_base += tot;
+      }
+      __syncthreads();
+    }
+  }
+  const int n = min(s_base, SR_MAXC);
+  const int kept = min(n, max_keep);
+  if (tid == 0) counts[s] = kept;
+  for (int i = tid; i < n; i += SR_THREADS) {
+    const float si = s_score[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const float sj = s_score[j];
+      rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+    }
+    if (rank < max_keep) order[(size_t)s * max_keep + rank] = s_row[i];
+  }
+  for (int i = kept + tid; i < max_keep; i += SR_THREADS) order[(size_t)s * max_keep + i] = -1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -822,6 +982,35 @@ extern "C" int cf_post_process(const float* det, const float* calib, const float
                      trans_inv, B, K, (float)out_w, (float)out_h, out);
   return cf_check_launch("cf_post_process");
 }
+
+extern "C" int cf_decode_post(const cf_decode_args* a, const float* calib, const float* trans_inv, float* post,
+                             void* stream) {
+  CF_REQUIRE(a && a->scores && a->inds && a->classes && calib && trans_inv && post, "cf_decode_post: null buffer");
+  CF_REQUIRE(a->B > 0 && a->K > 0 && a->H > 0 && a->W > 0 && a->out_h > 0 && a->out_w > 0,
+             "cf_decode_post: bad geometry");
+  const int n = a->B * a->K;
+  hipLaunchKernelGGL(decode_post_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, *a, calib,
+                     trans_inv, post);
+  return cf_check_launch("cf_decode_post");
+}
+
+extern "C" int cf_serialize_nuscenes(const cf_serialize_args* a, void* stream) {
+  CF_REQUIRE(a && a->post && a->trans_matrix && a->velocity_matrix && a->rows, "cf_serialize_nuscenes: null buffer");
+  CF_REQUIRE(a->B > 0 && a->K > 0 && a->K <= 1024, "cf_serialize_nuscenes: bad geometry (K <= 1024)");
+  CF_REQUIRE((a->cs_rot == nullptr) == (a->pose_rot == nullptr), "cf_serialize_nuscenes: cs_rot and pose_rot go together");
+  const int n = a->B * a->K;
+  hipLaunchKernelGGL(serialize_rows_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, a->post, a->B,
+                     a->K, a->trans_matrix, a->velocity_matrix, a->cs_rot, a->pose_rot, a->rows, a->rotation);
+  if (a->n_samples > 0) {
+    CF_REQUIRE(a->sample_ptr && a->sample_frames && a->order && a->counts, "cf_serialize_nuscenes: null sample tables");
+    CF_REQUIRE(a->max_per_sample >= 1, "cf_serialize_nuscenes: max_per_sample=%d", a->max_per_sample);
+    hipLaunchKernelGGL(serialize_topn_kernel, dim3(a->n_samples), dim3(SR_THREADS), 0, (hipStream_t)stream, a->rows,
+                       a->K, a->sample_ptr, a->sample_frames, a->max_per_sample, a->order, a->counts);
+  }
+  return cf_check_launch("cf_serialize_nuscenes");
+}
+
+extern "C" int cf_serialize_max_candidates(void) { return SR_MAXC; }
 
 extern "C" int cf_pillar_expand(const double* pc_2d, const double* pc_3d, const int32_t* counts, int B,
                                 int max_n, int n_rows, const double* calib, const double* trans, int H, int W,

@@ -16,15 +16,13 @@ DET_FIELDS = [("scores", 1), ("classIds", 1), ("centers", 2), ("bboxes", 4), ("r
 DET_WIDTH = sum(n for _, n in DET_FIELDS)
 
 
-def decode_packed(outputs, outputSize=(112, 200), K=100, norm2d=False):
-    """-> (det (B,K,33) f32, present-field names).  Same side effect on `outputs` as the reference:
-    `rotation2` is renamed to `rotation` in the caller's dict (decode.py:120-121)."""
+def _peaks_and_maps(outputs, K):
     assert isinstance(outputs, list), "output must be a list of dictionaries"
     if len(outputs) != 1:
         raise NotImplementedError("the DLA-34 model yields one output layer; multi-layer decode is not on the path")
     out = outputs[0]
     if "heatmap" not in out:
-        return None, []
+        return None
     if "uncertainty" in out:
         raise NotImplementedError("uncertainty head (TRAIN.UNCERTAINTY_LOSS) is outside the hot path")
     heat = out["heatmap"]
@@ -37,14 +35,40 @@ def decode_packed(outputs, outputSize=(112, 200), K=100, norm2d=False):
             "rot": out.get("rotation"), "dim": out.get("dimension"),
             "amodal": out.get("amodal_offset"), "att": out.get("nuscenes_att"),
             "vel": out.get("velocity")}
-    det = ops.decode_gather(scores, inds, classes, maps, H, W, outputSize, norm2d)
     present = ["scores", "classIds", "centers"]
     for name, key in (("bboxes", "wh"), ("rotation", "rot"), ("dimension", "dim"),
                       ("amodal_offset", "amodal"), ("nuscenes_att", "att"), ("velocity", "vel"),
                       ("depth", "depth")):
         if maps[key] is not None:
             present.append(name)
+    return scores, inds, classes, maps, H, W, present
+
+
+def decode_packed(outputs, outputSize=(112, 200), K=100, norm2d=False):
+    """-> (det (B,K,33) f32, present-field names).  Same side effect on `outputs` as the reference:
+    `rotation2` is renamed to `rotation` in the caller's dict (decode.py:120-121)."""
+    r = _peaks_and_maps(outputs, K)
+    if r is None:
+        return None, []
+    scores, inds, classes, maps, H, W, present = r
+    det = ops.decode_gather(scores, inds, classes, maps, H, W, outputSize, norm2d)
     return det, present
+
+
+def decode_post_packed(outputs, calibs, trans_inv, outputSize=(112, 200), K=100, norm2d=False, want_det=False):
+    """fusionDecode + postProcess in one gather launch (cf_decode_post) -> post (B,K,54) [, det (B,K,33)]:
+    the rows `postprocess.unpack_post` names - what Detector.post_process / the evaluation loop hand on
+    (detector.py:343-349, model/progressBar.py:95-110) and what the multi-GPU all-gather ships.
+    trans_inv: (2,3) f32 device tensor from postprocess.inverse_affine.  Needs the full 3D head set."""
+    r = _peaks_and_maps(outputs, K)
+    if r is None:
+        raise ValueError("decode_post_packed: outputs hold no heatmap")
+    scores, inds, classes, maps, H, W, present = r
+    if any(v is None for v in maps.values()):
+        raise NotImplementedError("decode_post_packed needs the full 3D detection head set")
+    B = scores.shape[0]
+    return ops.decode_post(scores, inds, classes, maps, H, W, outputSize,
+                           calibs.reshape(B, 3, 4).float().contiguous(), trans_inv, norm2d, want_det)
 
 
 def unpack_detections(det, present=None):

@@ -1,0 +1,124 @@
+"""`Detector`: the reference's inference driver (src/lib/detector.py:21-113, 189-349, 397-470) on the HIP
+path, end to end on the device:
+
+    uint8 camera frames + raw radar sweeps
+      -> preProcessImages        (cf_preprocess_images:   detector.py:206-234)
+      -> radar_to_pc_dep         (cf_radar_ingest + cf_pillar_expand:  detector.py:257-292)
+      -> model(images, pc_dep=, calib=)                   (detector.py:423)
+      -> fusionDecode + postProcess in one gather launch  (cf_decode_post: detector.py:343-349, 397-426)
+      -> merge_outputs                                    (detector.py:428-470)
+
+Only the raw bytes (frames, sweeps, calibration) cross PCIe; nothing is warped, projected, sorted,
+decoded or unprojected on the host.  Visualisation, file loading by path (cv2.imread) and the debug
+windows of the reference are outside the hot path."""
+import numpy as np
+import torch
+
+from . import _lib
+from .decode import decode_post_packed
+from .model import getModel
+from .pointcloud import getAffineTransform, radar_to_pc_dep
+from .postprocess import inverse_affine, unpack_post
+from .preprocess import NUSCENES_MEAN, NUSCENES_STD, preProcessImages
+
+FOCAL_LENGTH = 1200          # datasets/nuscenes.py:34 (used when an image has no calibration)
+
+
+class Detector(object):
+    def __init__(self, config, model=None, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.CfHipError("Detector runs on the GPU: the HIP path has no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.config = config
+        self.model = (model if model is not None else getModel(config)).to(self.device).eval()
+        self.mean, self.std = NUSCENES_MEAN, NUSCENES_STD
+        self._tinv = {}
+
+    # ------------------------------------------------------------------------------ pre_process
+    def pre_process(self, imageOrigins, img_infos, radar_pcs):
+        """-> images (B,3,inH,inW), pc_deps (B,3,outH,outW) or None, metas, calibs (B,3,4); all on the device."""
+        frames = imageOrigins if isinstance(imageOrigins, (list, tuple)) else [f for f in imageOrigins]
+        height, width = int(frames[0].shape[0]), int(frames[0].shape[1])
+        inH, inW = self.config.MODEL.INPUT_SIZE
+        outH, outW = self.config.MODEL.OUTPUT_SIZE
+        center = np.array([width / 2.0, height / 2.0], dtype=np.float32)
+        scale = max(height, width) * 1.0
+        transMatInput = getAffineTransform(center, scale, 0, [inW, inH])
+        transMatOutput = getAffineTransform(center, scale, 0, [outW, outH])
+        images = preProcessImages(imageOrigins, (inH, inW), self.mean, self.std, transMat=transMatInput,
+                                  device=self.device)
+        calibs, metas = [], []
+        for info in img_infos:
+            if info is not None and "calib" in info:
+                calib = np.array(info["calib"], dtype=np.float32)
+            else:
+                calib = np.array([[FOCAL_LENGTH, 0, center[0], 0], [0, FOCAL_LENGTH, center[1], 0], [0, 0, 1, 0]],
+                                 dtype=np.float32)
+            calibs.append(calib)
+            metas.append({"calib": calib, "center": center, "scale": scale, "height": height, "width": width,
+                          "outputHeight": outH, "outputWidth": outW, "inputHeight": inH, "inputWidth": inW,
+                          "transMatInput": transMatInput, "transMatOutput": transMatOutput})
+        pc_deps = None
+        if self.config.DATASET.RADAR_PC and radar_pcs is not None:
+            K3 = np.stack([np.asarray(i["camera_intrinsic"], np.float64).reshape(3, 3) for i in img_infos])
+            wh = {(int(i["width"]), int(i["height"])) for i in img_infos}
+            if len(wh) != 1:
+                raise ValueError("all frames of a batch must share one image size")
+            pc_deps = radar_to_pc_dep(radar_pcs, K3, wh.pop(), np.stack([np.asarray(i["calib"], np.float64)
+                                                                          for i in img_infos]),
+                                      transMatOutput, (outH, outW), max_dist=float(self.config.DATASET.MAX_PC_DIST),
+                                      z_offset=float(self.config.DATASET.PC_Z_OFFSET),
+                                      pillar_dims=tuple(self.config.DATASET.PILLAR_DIMS), device=self.device)
+        calibs = torch.from_numpy(np.stack(calibs, axis=0)).to(self.device)
+        return images, pc_deps, metas, calibs
+
+    # ---------------------------------------------------------------------------------- process
+    @torch.no_grad()
+    def process(self, images, calibs, pc_dep=None, meta=None):
+        """forward + decode + postProcess -> (outputs, post (B,K,54))."""
+        outputs = self.model(images, pc_dep=pc_dep, calib=calibs)
+        outH, outW = self.config.MODEL.OUTPUT_SIZE
+        key = (float(meta["center"][0]), float(meta["center"][1]), float(meta["scale"]), outH, outW)
+        tinv = self._tinv.get(key)
+        if tinv is None:
+            tinv = self._tinv[key] = torch.from_numpy(
+                inverse_affine(meta["center"], meta["scale"], (outW, outH))).to(self.device)
+        post = decode_post_packed(outputs, calibs, tinv, outputSize=(outH, outW), K=int(self.config.MODEL.K),
+                                  norm2d=bool(self.config.MODEL.NORM_2D))
+        return outputs, post
+
+    @staticmethod
+    def merge_outputs(detects):
+        """detector.py:428-470 on host copies of the post-processed fields."""
+        keep = (detects["scores"] > -1) & torch.all(detects["dimension"] > 0, dim=2)
+        B = detects["scores"].shape[0]
+        boxes = [[] for _ in range(B)]
+        for b in range(B):
+            for j in torch.nonzero(keep[b]).flatten().tolist():
+                boxes[b].append({"class": detects["classIds"][b, j], "score": detects["scores"][b, j],
+                                 "dimension": detects["dimension"][b, j], "location": detects["locations"][b, j],
+                                 "yaw": detects["yaws"][b, j], "bboxes": detects["bboxes"][b, j],
+                                 "bboxes3d": detects["bboxes3d"][b, j],
+                                 "nuscenes_att": detects["nuscenes_att"][b, j],
+                                 "velocity": detects["velocity"][b, j]})
+        return boxes
+
+    # -------------------------------------------------------------------------------------- run
+    def run(self, imgInput, img_info=None, radar_pc=None, merge=True):
+        """imgInput: (H,W,3) uint8 ndarray, a list of them, or a (B,H,W,3) uint8 tensor; img_info: dict or list of
+        dicts (`calib`, and for radar `camera_intrinsic`, `width`, `height`); radar_pc: (R,N) array or list.
+        -> {"outputs", "post" (B,K,54) device, "detects" (dict of host tensors), "predictBoxes"}."""
+        if isinstance(imgInput, np.ndarray) and imgInput.ndim == 3:
+            imgInput = [imgInput]
+        if not isinstance(img_info, (list, tuple)):
+            img_info = [img_info]
+            radar_pc = [radar_pc] if radar_pc is not None else None
+        with torch.cuda.device(self.device):
+            images, pc_dep, metas, calibs = self.pre_process(imgInput, img_info, radar_pc)
+            outputs, post = self.process(images, calibs, pc_dep, metas[0])
+        ret = {"outputs": outputs, "post": post, "metas": metas}
+        if merge:
+            detects = {k: v.cpu() for k, v in unpack_post(post).items()}
+            ret["detects"] = detects
+            ret["predictBoxes"] = self.merge_outputs(detects)
+        return ret

@@ -288,11 +288,9 @@ def frustum_assoc(inds, depth, wh, dim, rot, calib, pc_dep, max_pc_dist=60.0, wa
     return (pc_hm, pc_hm_nhwc4) if want_nhwc4 else pc_hm
 
 
-def decode_gather(scores, inds, classes, maps: dict, H, W, out_hw, norm2d=False):
-    """maps: optional NCHW tensors under reg/wh/depth/rot/dim/amodal/att/vel -> det (B,K,33)."""
+def _decode_args(scores, inds, classes, maps: dict, H, W, out_hw, norm2d, det):
     _need_cuda(scores, inds, classes)
     B, K = scores.shape
-    det = torch.empty((B, K, 33), device=scores.device, dtype=torch.float32)
     a = _lib.DecodeArgs()
     a.scores, a.inds, a.classes = scores.data_ptr(), inds.data_ptr(), classes.data_ptr()
     keep = []
@@ -304,9 +302,72 @@ def decode_gather(scores, inds, classes, maps: dict, H, W, out_hw, norm2d=False)
         setattr(a, name, _lib.ptr(t))
     a.B, a.K, a.H, a.W = B, K, H, W
     a.out_h, a.out_w, a.norm2d = int(out_hw[0]), int(out_hw[1]), int(bool(norm2d))
-    a.det = det.data_ptr()
+    a.det = _lib.ptr(det)
+    return a, keep
+
+
+def decode_gather(scores, inds, classes, maps: dict, H, W, out_hw, norm2d=False):
+    """maps: optional NCHW tensors under reg/wh/depth/rot/dim/amodal/att/vel -> det (B,K,33)."""
+    B, K = scores.shape
+    det = torch.empty((B, K, 33), device=scores.device, dtype=torch.float32)
+    a, _keep = _decode_args(scores, inds, classes, maps, H, W, out_hw, norm2d, det)
     _lib.check(_lib.load().cf_decode_gather(C.byref(a), _lib.stream_ptr()), "cf_decode_gather")
     return det
+
+
+def decode_post(scores, inds, classes, maps: dict, H, W, out_hw, calib, trans_inv, norm2d=False, want_det=False):
+    """cf_decode_post: decode rows and postProcess rows in one launch -> post (B,K,54) [, det (B,K,33)].
+    calib (B,3,4) f32, trans_inv (2,3) f32 device (output map -> source image affine)."""
+    _need_cuda(calib, trans_inv)
+    B, K = scores.shape
+    dev = scores.device
+    det = torch.empty((B, K, 33), device=dev, dtype=torch.float32) if want_det else None
+    post = torch.empty((B, K, 54), device=dev, dtype=torch.float32)
+    a, _keep = _decode_args(scores, inds, classes, maps, H, W, out_hw, norm2d, det)
+    if calib.dtype != torch.float32 or not calib.is_contiguous() or calib.numel() != B * 12:
+        raise _lib.CfHipError("cf_decode_post: calib must be contiguous float32 (B,3,4)")
+    if trans_inv.dtype != torch.float32 or not trans_inv.is_contiguous() or trans_inv.numel() != 6:
+        raise _lib.CfHipError("cf_decode_post: trans_inv must be contiguous float32 (2,3)")
+    _lib.check(_lib.load().cf_decode_post(C.byref(a), calib.data_ptr(), trans_inv.data_ptr(), post.data_ptr(),
+                                          _lib.stream_ptr()), "cf_decode_post")
+    return (post, det) if want_det else post
+
+
+def serialize_nuscenes(post, trans_matrix, velocity_matrix, cs_rot=None, pose_rot=None, sample_ptr=None,
+                       sample_frames=None, max_per_sample=500):
+    """cf_serialize_nuscenes -> rows (B*K,12) f32, rotation (B*K,4) f64, order (S,max) i32, counts (S) i32
+    (order / counts are None without the sample tables)."""
+    _need_cuda(post, trans_matrix, velocity_matrix)
+    B, K, w = post.shape
+    dev = post.device
+    for t, dt, n in ((post, torch.float32, B * K * 54), (trans_matrix, torch.float32, B * 16),
+                     (velocity_matrix, torch.float32, B * 16)):
+        if t.dtype != dt or not t.is_contiguous() or t.numel() != n:
+            raise _lib.CfHipError("cf_serialize_nuscenes: wrong dtype / shape / non-contiguous input")
+    a = _lib.SerializeArgs()
+    a.post, a.B, a.K = post.data_ptr(), B, K
+    a.trans_matrix, a.velocity_matrix = trans_matrix.data_ptr(), velocity_matrix.data_ptr()
+    if (cs_rot is None) != (pose_rot is None):
+        raise _lib.CfHipError("cf_serialize_nuscenes: cs_rot and pose_rot go together")
+    for q in (cs_rot, pose_rot):
+        if q is not None and (q.dtype != torch.float64 or not q.is_contiguous() or q.numel() != B * 4 or not q.is_cuda):
+            raise _lib.CfHipError("cf_serialize_nuscenes: quaternions must be contiguous float64 (B,4) on the device")
+    a.cs_rot, a.pose_rot = _lib.ptr(cs_rot), _lib.ptr(pose_rot)
+    rows = torch.empty((B * K, 12), device=dev, dtype=torch.float32)
+    rotation = torch.empty((B * K, 4), device=dev, dtype=torch.float64)
+    a.rows, a.rotation = rows.data_ptr(), rotation.data_ptr()
+    order = counts = None
+    if sample_ptr is not None:
+        _need_cuda(sample_ptr, sample_frames)
+        if sample_ptr.dtype != torch.int32 or sample_frames.dtype != torch.int32:
+            raise _lib.CfHipError("cf_serialize_nuscenes: sample tables must be int32")
+        S = sample_ptr.numel() - 1
+        order = torch.empty((S, max_per_sample), device=dev, dtype=torch.int32)
+        counts = torch.empty((S,), device=dev, dtype=torch.int32)
+        a.n_samples, a.sample_ptr, a.sample_frames = S, sample_ptr.data_ptr(), sample_frames.data_ptr()
+        a.max_per_sample, a.order, a.counts = int(max_per_sample), order.data_ptr(), counts.data_ptr()
+    _lib.check(_lib.load().cf_serialize_nuscenes(C.byref(a), _lib.stream_ptr()), "cf_serialize_nuscenes")
+    return rows, rotation, order, counts
 
 
 def pillar_expand(pc_2d, pc_3d, counts, calib, trans, out_hw, pillar_dims=(1.5, 0.2, 0.2),

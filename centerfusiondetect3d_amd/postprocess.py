@@ -22,6 +22,10 @@ def inverse_affine(center, scale, out_wh):
     return np.linalg.inv(np.vstack([fwd, [0.0, 0.0, 1.0]]))[:2].astype(np.float32)
 
 
+def inverse_affine_device(center, scale, out_wh, device):
+    return torch.from_numpy(inverse_affine(center, scale, out_wh)).to(device)
+
+
 def post_process_packed(det, calibs, center, scale, height, width):
     """det (B,K,33) device tensor -> (B,K,54) device tensor."""
     if not det.is_cuda:

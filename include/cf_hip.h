@@ -311,6 +311,49 @@ int cf_decode_gather(const cf_decode_args* a, void* stream);
 int cf_post_process(const float* det, const float* calib, const float* trans_inv, int B, int K,
                     int out_h, int out_w, float* out, void* stream);
 
+/* cf_decode_post: cf_decode_gather and cf_post_process in ONE launch (the 33-float row never leaves
+ * registers): model/decode.py:10-174 followed by utils/postProcess.py:13-85, as Detector.process +
+ * Detector.post_process chain them (detector.py:343-349, 397-426) and as the evaluation loop does
+ * (model/progressBar.py:95-110).  post (B,K,54) as cf_post_process writes it; a->det (B,K,33) is
+ * optional (NULL: only the final rows).  Bit-identical to the two separate calls. */
+int cf_decode_post(const cf_decode_args* a, const float* calib, const float* trans_inv, float* post,
+                   void* stream);
+
+/* cf_serialize_nuscenes: post-processed detections -> the numeric content of the nuScenes result
+ * file, replaces dataset/datasets/nuscenes.py:416-482 (getEvalFormatItem) and the per-sample merge +
+ * top-500 of nuscenes.py:536-553 (convert_eval_format); SURVEY §8(f) rank 4.
+ *   rows (B*K, 12) f32: [translation xyz = trans_matrix @ (location - (0, h, 0), 1), size (w, l, h),
+ *                        velocity xy = (velocity_matrix @ (v, 0))[:2], score, class index 0..9,
+ *                        attribute id 0..8 (0 = ""), keep = score > -1 && all dimensions > 0]
+ *   rotation (B*K, 4) f64 (optional): pose_rot * cs_rot * R_y(yaw), (w, x, y, z); NULL cs/pose: R_y(yaw)
+ *   order (n_samples, max_per_sample) i32: row indices (b*K + k) of each sample's best rows, best first,
+ *     -1 padded; counts (n_samples).  A sample's frames are sample_frames[sample_ptr[s] .. sample_ptr[s+1])
+ *     in image order (CSR); at most cf_serialize_max_candidates() kept rows per sample take part.
+ * The strings of the file (sample_token, detection_name, attribute_name) are joined on the host. */
+typedef struct cf_serialize_args {
+  const float* post;             /* (B,K,54) from cf_post_process / cf_decode_post                */
+  int32_t B, K;
+  const float* trans_matrix;     /* (B,4,4) f32 camera -> global (image_info["trans_matrix"])     */
+  const float* velocity_matrix;  /* (B,4,4) f32 (image_info["velocity_trans_matrix"])             */
+  const double* cs_rot;          /* (B,4) f64 calibrated-sensor quaternion, or NULL               */
+  const double* pose_rot;        /* (B,4) f64 ego-pose quaternion, or NULL                        */
+  float* rows;                   /* (B*K,12)                                                      */
+  double* rotation;              /* (B*K,4) or NULL                                               */
+  int32_t n_samples;             /* 0: rows only                                                  */
+  const int32_t* sample_ptr;     /* (n_samples+1)                                                 */
+  const int32_t* sample_frames;  /* (sample_ptr[n_samples]) frame indices                         */
+  int32_t max_per_sample;        /* 500 in the reference                                          */
+  int32_t* order;                /* (n_samples, max_per_sample)                                   */
+  int32_t* counts;               /* (n_samples)                                                   */
+} cf_serialize_args;
+int cf_serialize_nuscenes(const cf_serialize_args* a, void* stream);
+int cf_serialize_max_candidates(void);
+
+/* Weight packing is host-side Python (centerfusiondetect3d_amd/packing.py), not part of this ABI: it
+ * runs once per load_state_dict (BatchNorm fold, slot tables, split hi/lo planes, MFMA fragment order)
+ * and the reference's own host side is Python.  The layouts the kernels expect are documented at each
+ * argument block above and in DESIGN.md section 3. */
+
 const char* cf_last_error(void);
 int cf_abi_version(void);
 

@@ -141,8 +141,12 @@ def sigmoid_depth(x):
 
 
 def forward(sd, x, pc_dep=None, calib=None, radar=True, frustum=True, K=100,
-            max_pc_dist=60.0, num_classes=10, hp="detectHead_0"):
-    """model(x, pc_dep=, calib=) in eval mode -> [dict] (base_model.py:67-106)."""
+            max_pc_dist=60.0, num_classes=10, hp="detectHead_0", pc_hm_override=None):
+    """model(x, pc_dep=, calib=) in eval mode -> [dict] (base_model.py:67-106).
+
+    pc_hm_override (tests only): use this (B,3,H,W) frustum map instead of computing it - lets a
+    float64 evaluation share the DISCRETE decisions (top-k order, depth gate) of the fp32 run, so
+    that the comparison measures arithmetic error and not a flipped box."""
     heads, head_conv = head_spec(radar, num_classes)
     feat = img2feats(sd, x)
     y = {}
@@ -157,7 +161,10 @@ def forward(sd, x, pc_dep=None, calib=None, radar=True, frustum=True, K=100,
         return [y]
     y["pc_hm_in"] = pc_dep[:, :1]
     assert frustum, "non-frustum middle fusion is outside the hot path"
-    pc_hm = frustum_ref.pc_frustum_heatmap(y, pc_dep, calib, K, max_pc_dist)
+    if pc_hm_override is not None:
+        pc_hm = pc_hm_override.to(feat.dtype)
+    else:
+        pc_hm = frustum_ref.pc_frustum_heatmap(y, pc_dep, calib, K, max_pc_dist)
     y["pc_hm"] = pc_hm[:, 0:1]
     sec = torch.cat([feat, pc_hm], dim=1)
     for h in SECONDARY_HEADS:

@@ -58,6 +58,25 @@ def test_struct_layouts_match_c(tmp_path):
                    _lib.DcnArgs.workspace.offset, _lib.DcnArgs.out_split_bf16.offset]
 
 
+def test_serialize_struct_layout(tmp_path):
+    from centerfusiondetect3d_amd import _lib
+    prog = tmp_path / "sz2.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cf_hip.h"\nint main(){'
+                    'printf("%zu %zu %zu %zu\\n", sizeof(cf_serialize_args), offsetof(cf_serialize_args, rows),'
+                    'offsetof(cf_serialize_args, max_per_sample), offsetof(cf_serialize_args, counts));return 0;}')
+    exe = tmp_path / "sz2"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == [ctypes.sizeof(_lib.SerializeArgs), _lib.SerializeArgs.rows.offset,
+                   _lib.SerializeArgs.max_per_sample.offset, _lib.SerializeArgs.counts.offset]
+    lib = _lib.load()
+    assert lib.cf_serialize_max_candidates() >= 600
+    a = _lib.SerializeArgs()
+    assert lib.cf_serialize_nuscenes(ctypes.byref(a), None) == -22
+    d = _lib.DecodeArgs()
+    assert lib.cf_decode_post(ctypes.byref(d), None, None, None, None) == -22
+
+
 def test_argument_validation_without_gpu():
     """Entry points reject bad arguments before touching the device."""
     from centerfusiondetect3d_amd import _lib

@@ -44,6 +44,38 @@ def test_gather_detections_gloo_ws2(n_frames, equal_hint):
         assert same and shape == (n_frames, 100, 33)
 
 
+def _worker_async(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from centerfusiondetect3d_amd.distributed import DetectionGatherer, assume_equal_shards
+    assume_equal_shards(True)
+    g = DetectionGatherer()
+    ok = True
+    pending = []
+    for step in range(3):                                    # three steps in flight before the first wait
+        mine = torch.full((4, 100, 54), float(10 * step + rank))
+        pending.append((step, g.submit(mine)))
+    for step, h in pending:
+        out = h.wait()
+        exp = torch.cat([torch.full((4, 100, 54), float(10 * step + r)) for r in range(world)], 0)
+        ok = ok and bool(torch.equal(out, exp))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_overlapped_gatherer_gloo_ws2():
+    """DetectionGatherer (async all-gather of the final (B,K,54) rows, several steps in flight)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_async, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in procs)
+    [p.join(30) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert res == [(0, True), (1, True)]
+
+
 def test_shard_range_balanced():
     from centerfusiondetect3d_amd.distributed import shard_range
     for n in (0, 1, 7, 16, 128, 129):

@@ -2,15 +2,18 @@
 vectors produced by the reference's own forward and (b) the CPU oracle, through the drop-in
 boundary `model(images, pc_dep=, calib=) -> [dict]`.
 
-Tolerance (north star "within 1e-3 relative fp32"): |got - ref| <= 1e-3*|ref| + 4e-4*max|ref| per
-element (elements near zero are judged against the map's scale, 2.5x tighter than the normwise
-1e-3); the index path (top-k, painted pixel set) must be identical.  The absolute term has to cover
-TWO fp32 evaluations: the DCN neck amplifies rounding ~100x at samples that sit on a cell or image
-border, and against a float64 run of the same network the reference's own fp32 arithmetic is off by
-up to ~1e-4 normwise in the worst of ~10^5..10^6 elements (tools/stage_error.py) - as is this
-implementation, whose RMS error equals the fp32 reference's within a few per cent
-(test_accuracy_anchored_on_float64 holds it to 1.25x).  The worst normwise error actually observed is
-printed (pytest -s) and quoted in DESIGN.md."""
+Tolerance (north star "within 1e-3 relative fp32"): per element
+    |got - ref| <= 1e-3*|ref| + A*max|ref|,      A = max(2e-4, 3*e32 + 2e-5)
+where e32 is MEASURED in the test itself: the max-norm error of the fp32 oracle (= the reference's own
+fp32 arithmetic) against the same oracle evaluated in float64 on the same inputs.  Why e32 enters: `ref`
+is an fp32 evaluation, and two correct fp32 evaluations of this network can differ by the sum of their
+own errors - the DCN neck amplifies rounding ~100x at samples that sit on a cell or image border, so
+e32 is ~1e-5 at small sizes and up to ~1e-4 in the worst of ~10^6 elements at 448x800.  The HIP path is
+separately held to |hip - fp64| <= 2*e32 + 2e-5 and RMS <= 1.25x the fp32 oracle's
+(test_accuracy_anchored_on_float64, on the bench configuration itself), which gives 3*e32 + 2e-5 against
+`ref` by the triangle inequality.  Where no float64 run is made the floor A = 2e-4 applies.  Both numbers
+(observed error, allowed A) are printed (pytest -s).  The index path (top-k, painted pixel set) must be
+identical."""
 import os
 
 import numpy as np
@@ -23,7 +26,29 @@ from oracle import model_ref, decode_ref
 from tests.golden import cases
 
 RTOL = 1e-3
-ATOL_SCALE = 4e-4
+ATOL_FLOOR = 2e-4
+
+
+def _atol(e32=None):
+    return ATOL_FLOOR if e32 is None else max(ATOL_FLOOR, 3.0 * e32 + 2e-5)
+
+
+def _fp32_noise(sd, x, pc_dep, calib, radar, ref32=None):
+    """{output: max-norm error of the fp32 oracle against the float64 oracle} on these inputs.  The float64
+    run shares the fp32 run's frustum map (discrete decisions), so only arithmetic differs."""
+    from oracle import frustum_ref
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    with torch.no_grad():
+        r32 = ref32 if ref32 is not None else model_ref.forward(sd, x, pc_dep=pc_dep, calib=calib, radar=radar)[0]
+        hm = frustum_ref.pc_frustum_heatmap(r32, pc_dep, calib, 100, 60.0) if radar else None
+        r64 = model_ref.forward(sd64, x.double(), pc_dep=pc_dep.double() if radar else None, calib=calib,
+                                radar=radar, pc_hm_override=hm)[0]
+    noise = {}
+    for k, t in r64.items():
+        if k == "calib":
+            continue
+        noise[k] = float((r32[k].double() - t).abs().max()) / (float(t.abs().max()) + 1e-300)
+    return noise, r32, r64
 
 
 @pytest.fixture(scope="module")
@@ -40,47 +65,55 @@ def _model(radar, dev, input_size):
     return m.to(dev).eval()
 
 
-def _assert_maps_close(got, ref, name):
+def _assert_maps_close(got, ref, name, e32=None, scale=None):
+    """e32: measured fp32-vs-float64 error of this output (see the module docstring); scale: max|ref| of the
+    WHOLE map when `ref` is a sample of it."""
     got = got.detach().cpu().numpy()
     ref = ref.numpy() if isinstance(ref, torch.Tensor) else ref
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
-    scale = float(np.abs(ref).max()) + 1e-12
+    scale = (float(np.abs(ref).max()) if scale is None else float(scale)) + 1e-12
     err = np.abs(got - ref)
-    tol = RTOL * np.abs(ref) + ATOL_SCALE * scale
-    assert (err <= tol).all(), f"{name}: max err {err.max():.3e} (scale {scale:.3e}), " \
+    a = _atol(e32)
+    tol = RTOL * np.abs(ref) + a * scale
+    assert (err <= tol).all(), f"{name}: max err {err.max():.3e} (scale {scale:.3e}, allowed A {a:.2e}), " \
                                f"{int((err > tol).sum())} / {err.size} outside 1e-3"
-    print(f"[parity] {name:>16s}: max|err|/max|ref| = {err.max() / scale:.2e}")
+    print(f"[parity] {name:>16s}: max|err|/max|ref| = {err.max() / scale:.2e}  (allowed abs term {a:.2e}"
+          + (f", fp32-vs-fp64 {e32:.2e})" if e32 is not None else ", floor)"))
     return float(err.max() / scale)
 
 
-def test_accuracy_anchored_on_float64(dev):
+@pytest.mark.parametrize("radar,B,H,W", [(False, 1, 256, 416), (True, 2, 448, 800)],
+                         ids=["centernet_256x416", "centerfusion_middle_448x800_bs2"])
+def test_accuracy_anchored_on_float64(dev, radar, B, H, W):
     """The yardstick that does not depend on anybody's fp32 rounding: the oracle evaluated in float64.
     The HIP path must be as close to it as the reference's own fp32 arithmetic (the fp32 oracle) is -
-    RMS error within 1.25x, worst element within 2x (+ a floor for maps both get right to 1e-6)."""
-    from centerfusiondetect3d_amd import getModel, centernet_config
-    H, W = 256, 416
-    sd = cases.tuned_state_dict(radar=False, seed=0)
-    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-    x, _, calib = cases.model_inputs(1, H, W, seed=5, radar=False)
-    with torch.no_grad():
-        r32 = model_ref.forward(sd, x, calib=calib, radar=False)[0]
-        r64 = model_ref.forward(sd64, x.double(), calib=calib, radar=False)[0]
-    m = getModel(centernet_config((H, W)))
+    RMS error within 1.25x, worst element within 2x (+ a floor for maps both get right to 1e-6) - on
+    EVERY output, including the secondary heads (three chained split-bf16 layers behind the frustum map)
+    of the configuration bench.py measures (Centerfusion_Middle, 448x800)."""
+    from centerfusiondetect3d_amd import getModel, centernet_config, centerfusion_middle_config
+    sd = cases.tuned_state_dict(radar=radar, seed=0)
+    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=5, radar=radar, n_points=(80, 200))
+    noise, r32, r64 = _fp32_noise(sd, x, pc_dep, calib, radar)
+    m = getModel((centerfusion_middle_config if radar else centernet_config)((H, W)))
     m.load_state_dict(sd)
     m = m.to(dev).eval()
     with torch.no_grad():
-        y = m(x.to(dev), calib=calib.to(dev))[0]
+        y = m(x.to(dev), pc_dep=pc_dep.to(dev) if radar else None, calib=calib.to(dev))[0]
+    if radar:
+        # discrete path first: same painted map as the fp32 oracle, bit for bit
+        assert torch.equal(y["pc_hm"].cpu(), r32["pc_hm"]) and int((r32["pc_hm"] != 0).sum()) > 0
     for k, t in r64.items():
         if k == "calib":
             continue
         g, c = y[k].double().cpu(), r32[k].double()
-        scale = float(t.abs().max())
-        rms = float(t.pow(2).mean().sqrt())
+        scale = float(t.abs().max()) + 1e-300
+        rms = float(t.pow(2).mean().sqrt()) + 1e-300
         e_gpu, e_cpu = float((g - t).abs().max()) / scale, float((c - t).abs().max()) / scale
         r_gpu, r_cpu = float((g - t).pow(2).mean().sqrt()) / rms, float((c - t).pow(2).mean().sqrt()) / rms
         print(f"[fp64] {k:>16s}: max-norm hip {e_gpu:.2e} fp32-oracle {e_cpu:.2e} | rms hip {r_gpu:.2e} fp32-oracle {r_cpu:.2e}")
         assert r_gpu <= 1.25 * r_cpu + 2e-6, (k, r_gpu, r_cpu)
         assert e_gpu <= 2.0 * e_cpu + 2e-5, (k, e_gpu, e_cpu)
+        _assert_maps_close(y[k], r32[k], k, e32=noise[k])
 
 
 @pytest.mark.parametrize("tag,radar,B,H,W", [("centerfusion_small", True, 2, 128, 160),
@@ -123,12 +156,13 @@ def test_forward_and_decode_fullres_vs_reference_samples(dev, golden_dir):
     with torch.no_grad():
         out = m(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))
     y = out[0]
+    noise, r32, _ = _fp32_noise(cases.tuned_state_dict(radar=True, seed=0), x, pc_dep, calib, True)
     for k, v in y.items():
         if k == "calib":
             continue
         assert tuple(v.shape[2:]) == (112, 200)
         flat = v.reshape(-1).cpu()
-        _assert_maps_close(flat[g[f"idx_{k}"]], g[f"val_{k}"], k)
+        _assert_maps_close(flat[g[f"idx_{k}"]], g[f"val_{k}"], k, e32=noise[k], scale=float(r32[k].abs().max()))
     assert int((y["pc_hm"] != 0).sum()) == int(g["n_painted"])
     det = fusionDecode(out, outputSize=(112, 200), K=100, norm2d=False)
     assert np.array_equal(det["classIds"].cpu().numpy(), g["det_classIds"])      # index path
@@ -268,6 +302,18 @@ def test_config_c2_full_size_properties(dev):
             det, _ = decode_packed(part, (112, 200), 100)
             assert torch.equal(det, det_full[lo:hi])
     assert int((full[0]["pc_hm"] != 0).sum()) > 0
+    # ... and frames of the bs=16 batch against the oracle (not only against the HIP path itself); `full` had
+    # rotation2 renamed to rotation by the decode above, as the reference's decode does
+    sd = cases.tuned_state_dict(radar=True, seed=0)
+    for f in (3, 12):
+        sl = slice(f, f + 1)
+        noise, r32, _ = _fp32_noise(sd, x[sl], pc_dep[sl], calib[sl], True)
+        for k, v in r32.items():
+            if k in ("calib", "rotation"):
+                continue
+            kk = "rotation" if k == "rotation2" else k
+            _assert_maps_close(full[0][kk][sl], v, f"frame{f}.{k}", e32=noise[k])
+        assert torch.equal(full[0]["pc_hm"][sl].cpu(), r32["pc_hm"])
 
 
 def test_forward_is_reproducible_behind_unrelated_kernels(dev):
@@ -377,7 +423,7 @@ def test_stage_buffers_match_reference_submodules(dev, golden_dir, tag, radar, B
         ref = g[f"stage_val_{n}"]
         scale = float(np.abs(ref).max()) + 1e-12
         err = np.abs(got - ref)
-        assert (err <= RTOL * np.abs(ref) + ATOL_SCALE * scale).all(), (n, float(err.max() / scale))
+        assert (err <= RTOL * np.abs(ref) + ATOL_FLOOR * scale).all(), (n, float(err.max() / scale))
         print(f"[stage] {n:>5s}: max|err|/max|ref| = {err.max() / scale:.2e}")
         checked += 1
     assert checked == 10

@@ -116,3 +116,88 @@ def test_affine_transform_matches_oracle():
         a = getAffineTransform((w / 2, h / 2), float(max(w, h)), 0, out)
         b = pillar_ref.affine_transform_matrix((w / 2, h / 2), float(max(w, h)), out)
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------- legacy checkpoint names
+def _legacy_fixture():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "legacy_keys.npz"))
+
+
+@pytest.mark.parametrize("tag,cfg", [("centerfusion", centerfusion_middle_config), ("centernet", centernet_config)])
+def test_legacy_names_follow_the_reference_mapping(tag, cfg):
+    """tests/golden/legacy_keys.npz holds, for every key of our state_dict, the names the REFERENCE's
+    toggleWeightName gives it (model/model.py:169-250; v1 = hm./dep_sec./actf/conv.conv_offset_mask, v2 = bare
+    head names): our mapper agrees in both directions."""
+    from centerfusiondetect3d_amd import checkpoint as ck
+    g = _legacy_fixture()
+    new, old, old2 = (list(g[f"{tag}_{s}"]) for s in ("new", "old", "oldv2"))
+    m = getModel(cfg((64, 64)))
+    assert list(m.state_dict().keys()) == new
+    assert sum(a != b for a, b in zip(new, old)) > 150
+    for k, a, b in zip(new, old, old2):
+        assert ck.to_new_name(a) == k and ck.to_new_name(b) == k and ck.to_new_name(k) == k
+        assert ck.to_new_name("module." + a) == k
+        assert ck.to_old_name(k, 1) == a and ck.to_old_name(k, 2) == b
+
+
+def test_legacy_keyed_checkpoint_loads(tmp_path):
+    """A DataParallel-prefixed, legacy-keyed checkpoint with one wrong-shaped and one unknown entry loads through
+    elastic_load_state_dict / loadModel with the reference's semantics (rename, skip shape mismatch, drop unknown)."""
+    from centerfusiondetect3d_amd import checkpoint as ck
+    g = _legacy_fixture()
+    new, old = list(g["centerfusion_new"]), list(g["centerfusion_old"])
+    cfg = centerfusion_middle_config((64, 64))
+    gen = torch.Generator().manual_seed(3)
+    m0 = getModel(cfg)
+    src = {k: (torch.randn(v.shape, generator=gen) if v.is_floating_point() else v.clone())
+           for k, v in m0.state_dict().items()}
+    legacy = {"module." + o: src[k] for k, o in zip(new, old)}
+    assert "module.hm.0.weight" in legacy and "module.dla_up.ida_0.proj_1.conv.conv_offset_mask.weight" in legacy
+    legacy["module.hm.2.bias"] = torch.zeros(3)                         # wrong shape: the model keeps its own
+    legacy["module.some.unknown.key"] = torch.zeros(1)
+    m, rep = ck.elastic_load_state_dict(getModel(cfg), legacy)
+    assert rep["dropped"] == ["module.some.unknown.key"] and rep["skipped_shape"] == ["module.hm.2.bias"]
+    assert not rep["missing"]
+    for k, v in m.state_dict().items():
+        if k == "detectHead_0.heatmap.2.bias":
+            assert float(v[0]) == pytest.approx(-4.6)                       # untouched initial bias (detectHeads.py:93)
+        else:
+            assert torch.equal(v, src[k]), k
+    # loadModel from a file, as Detector.__init__ does (detector.py:29-31)
+    path = tmp_path / "ckpt.pth"
+    del legacy["module.hm.2.bias"], legacy["module.some.unknown.key"]
+    torch.save({"epoch": 7, "state_dict": legacy}, path)
+    cfg.MODEL.LOAD_DIR = str(path)
+    ckpt, m2, start = ck.loadModel(getModel(cfg), cfg)
+    assert ckpt["epoch"] == 7 and start == 1
+    for k, v in m2.state_dict().items():
+        if k != "detectHead_0.heatmap.2.bias":
+            assert torch.equal(v, src[k]), k
+
+
+def test_reference_loader_accepts_our_module():
+    """Where the reference is present (the build container): its own elasticLoadStateDict drives OUR module."""
+    import os, sys
+    if not os.path.isdir("/root/reference/src/lib"):
+        pytest.skip("reference tree not present on this machine")
+    from tests.golden import make_golden
+    saved_path, saved_mods = list(sys.path), dict(sys.modules)
+    try:
+        make_golden._install_inert_modules()
+        sys.path[:0] = ["/root/reference/src", "/root/reference/src/lib"]
+        from model.model import elasticLoadStateDict, toggleWeightName
+        cfg = centerfusion_middle_config((64, 64))
+        gen = torch.Generator().manual_seed(4)
+        src = {k: (torch.randn(v.shape, generator=gen) if v.is_floating_point() else v.clone())
+               for k, v in getModel(cfg).state_dict().items()}
+        legacy = {toggleWeightName(k, "old"): v for k, v in src.items()}
+        m = elasticLoadStateDict(getModel(cfg), legacy)
+        for k, v in m.state_dict().items():
+            assert torch.equal(v, src[k]), k
+    finally:
+        sys.path[:] = saved_path
+        for k in list(sys.modules):
+            if k not in saved_mods:
+                del sys.modules[k]
+        sys.modules.update(saved_mods)
