@@ -130,16 +130,17 @@ def cpu_model_name():
 
 def cpu_baseline(H, W, batch=16, runs=3, seed=0):
     """CPU oracle (our torch-fp32 restatement, kind 'port') per SURVEY.md §8(d): forward + decode timed on this
-    host with all granted cores - C2 (Centerfusion_Middle) at bs=`batch` and bs=1 and C1 (CenterNet) at bs=1,
-    median of `runs` after one warm-up.  `value` = the C2 bs=`batch` rate (the configuration `value` of the
-    contract line is quoted on); the other legs are listed under `runs`.  ~35 s of CPU work at the defaults."""
+    host with all granted cores - C2 (Centerfusion_Middle) at bs=1 and bs=`batch`, C1 (CenterNet) at bs=1; median of
+    `runs` after one warm-up for the bs=1 legs, ONE run for the bs=`batch` leg (29 s on 16 cores: three would triple
+    the bounded sample).  `value` = the better C2 rate (bs=1 is faster on this host: the oracle's DCN gather and the
+    fp32 maps of 16 frames fall out of cache); every leg is listed under `runs`.  ~35 s of CPU work at the defaults."""
     from oracle import model_ref, decode_ref
     rs = np.random.RandomState(seed)
     cores = cpu_threads()
     torch.set_num_threads(cores)
     calib1 = torch.tensor([[1266.4, 0, 816.3, 0], [0, 1266.4, 491.5, 0], [0, 0, 1, 0]])
 
-    def leg(radar, bs):
+    def leg(radar, bs, n_runs):
         sd = model_ref.make_state_dict(radar=radar, seed=seed)
         x = torch.from_numpy(rs.standard_normal((bs, 3, H, W)).astype(np.float32))
         pc_dep = None
@@ -153,21 +154,23 @@ def cpu_baseline(H, W, batch=16, runs=3, seed=0):
         ts = []
         with torch.no_grad():
             model_ref.forward(sd, x[:1], pc_dep=pc_dep[:1] if radar else None, calib=calib[:1], radar=radar)   # warm-up
-            for _ in range(runs):
+            for _ in range(n_runs):
                 t0 = time.perf_counter()
                 y = model_ref.forward(sd, x, pc_dep=pc_dep, calib=calib, radar=radar)
                 decode_ref.fusion_decode(y, (H // 4, W // 4), 100)
                 ts.append(time.perf_counter() - t0)
         med = float(np.median(ts))
-        return {"config": "C2 Centerfusion_Middle" if radar else "C1 CenterNet", "batch": bs,
+        return {"config": "C2 Centerfusion_Middle" if radar else "C1 CenterNet", "batch": bs, "runs": n_runs,
                 "median_s": round(med, 3), "frames_per_s": round(bs / med, 4)}
 
-    legs = [leg(True, batch), leg(True, 1), leg(False, 1)]
-    total = sum(l["median_s"] for l in legs) * runs
-    return {"value": legs[0]["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
+    legs = [leg(True, 1, runs), leg(True, batch, 1), leg(False, 1, runs)]
+    total = sum(l["median_s"] * l["runs"] for l in legs)
+    best = max(legs[:2], key=lambda l: l["frames_per_s"])
+    return {"value": best["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
             "cpu": cpu_model_name(),
-            "sample": f"torch-fp32 oracle forward+decode, 3x{H}x{W}: C2 bs={batch} (the value), C2 bs=1, C1 bs=1; "
-                      f"median of {runs} runs each after a 1-frame warm-up, ~{total:.0f} s of CPU work",
+            "sample": f"torch-fp32 oracle forward+decode, 3x{H}x{W}: C2 bs=1 x{runs}, C2 bs={batch} x1, C1 bs=1 x{runs} "
+                      f"after a 1-frame warm-up each, ~{total:.0f} s of CPU work; value = C2 at bs={best['batch']} "
+                      f"(its faster batch size on this host)",
             "runs": legs}
 
 
