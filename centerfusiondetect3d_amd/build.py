@@ -18,7 +18,7 @@ OBJ = os.path.join(PKG, "_build")
 LIB = os.path.join(PKG, "libcfhip.so")
 
 ARCH = "gfx950"
-COMMON = ["-O3", "-std=c++17", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
+COMMON = os.environ.get("CF_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", f"-I{os.path.join(ROOT, 'include')}", f"-I{CSRC}"]
 # (source, extra flags).  cf_post: the index path must not fuse mul+add (bit-exact slice bounds).
 SOURCES = [
     ("cf_gemm.hip", []),
