@@ -222,11 +222,11 @@ def main():
     ap.add_argument("--offset-std", type=float, default=0.01,
                     help="std of the synthetic conv_offset_mask weights: 0.01 -> offsets O(1-3 px) (C2); 0.04 -> O(8 px), "
                          "BASELINE config C4 (stresses the bilinear gather)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="sub-batches of the per-GPU batch on concurrent HIP streams (model.streams).  2 measures "
-                         "+4-5 %% (the other sub-batch fills under-filled launches) but kernels then overlap, so the "
-                         "per-launch roofline timing and the rocprofv3 trace (which serialises streams) stop "
-                         "describing the same thing: the contract line is taken on one stream")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="model.streams: backbone + neck as that many sub-batches on concurrent HIP streams (the other "
+                         "sub-batch fills launches that cannot fill the chip alone); the heads - the roofline kernel - "
+                         "run for the whole batch on the caller's stream, so their HIP-event durations overlap nothing.  "
+                         "1 = everything on one stream")
     ap.add_argument("--exact-fp32", action="store_true",
                     help="every product in exact fp32 (fp32 MFMA kernels with two-level summation; conv_f16 / heads_bf16 "
                          "off) instead of the default split-operand products - the accuracy reference build, 3.5x slower")

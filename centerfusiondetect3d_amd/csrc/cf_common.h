@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
+#include <mutex>
 #include "cf_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -20,6 +22,24 @@ void cf_set_error(const char* fmt, ...);
       return CF_EINVAL;          \
     }                            \
   } while (0)
+
+// Dynamic-LDS limit of one kernel: raised (never lowered) with hipFuncSetAttribute the first time a launch needs
+// more than what has been set.  One static instance per kernel / template instantiation; safe when several host
+// threads issue launches of the same kernel concurrently (the C ABI is re-entrant per stream).
+struct CfLdsLimit {
+  std::atomic<size_t> limit{0};
+  std::mutex m;
+  template <typename K>
+  void ensure(K kernel, size_t dyn, size_t floor_bytes) {
+    if (dyn <= limit.load(std::memory_order_acquire) && limit.load(std::memory_order_relaxed) > 0) return;
+    std::lock_guard<std::mutex> lk(m);
+    const size_t cur = limit.load(std::memory_order_relaxed);
+    if (cur > 0 && dyn <= cur) return;
+    const size_t v = dyn < floor_bytes ? floor_bytes : dyn;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
+    limit.store(v, std::memory_order_release);
+  }
+};
 
 static inline int cf_check_launch(const char* what) {
   hipError_t e = hipGetLastError();

@@ -20,6 +20,7 @@
 //
 // Replaces the 3x3 stride-1 convolutions of model/networks/dla.py:42-62 (BasicBlock conv1/conv2) and
 // the conv_offset_mask of model/networks/dla.py:406-414 (DeformConv) on the device.
+#include <stdlib.h>
 #include "cf_f16x3.h"
 
 namespace {
@@ -321,12 +322,8 @@ bool try_launch(Conv3F k, int batch, hipStream_t st) {
   if (WK > 1) dyn = dyn < (size_t)4 * RT * 2 * 16 * 64 * 4 ? (size_t)4 * RT * 2 * 16 * 64 * 4 : dyn;
   if (dyn > 160 * 1024) return false;
   auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB, T2>;
-  static size_t limit = 0;
-  if (dyn > limit) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(dyn < 65536 ? 65536 : dyn));
-    limit = dyn < 65536 ? 65536 : dyn;
-  }
+  static CfLdsLimit lds_limit;                // (one per template instantiation)
+  lds_limit.ensure(kernel, dyn, 65536);
   const dim3 grid((unsigned)blocks, (unsigned)((k.n_rt + WC * RT - 1) / (WC * RT)));
   hipLaunchKernelGGL(kernel, grid, dim3(NT), dyn, st, k);
   return true;
@@ -377,6 +374,27 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
     k.n_rounds = slices / WK;
     return slices % WK == 0;
   };
+  // dev override (tools/bench_conv_cfg.py): CF_CONV3_CFG="WC,WP,WK[,T2]" forces one of the instantiated tilings
+  if (const char* force = getenv("CF_CONV3_CFG")) {
+    int wc = 0, wp = 0, wk = 0, t2f = 0;
+    if (sscanf(force, "%d,%d,%d,%d", &wc, &wp, &wk, &t2f) >= 3 && cfg(wk)) {
+      const int key = wc * 100 + wp * 10 + wk;
+      bool done = false;
+      if (a->N_pad >= 64) {
+        switch (key) {
+          case 221: done = try_launch<2, 2, 1, 2, 6, true, 2>(k, B, st); break;
+          case 212: done = try_launch<2, 1, 2, 2, 4, true, 2>(k, B, st); break;
+          case 114: done = try_launch<1, 1, 4, 2, 12, false, 2>(k, B, st); break;
+          case 122: done = try_launch<1, 2, 2, 2, 10, false, 2>(k, B, st); break;
+          case 411: done = try_launch<4, 1, 1, 2, 4, true, 2>(k, B, st); break;
+          case 421: done = try_launch<4, 2, 1, 2, 2, true, 1>(k, B, st); break;
+          case 141: done = t2f ? try_launch<1, 4, 1, 2, 6, true, 2, true>(k, B, st) : try_launch<1, 4, 1, 2, 6, true, 2>(k, B, st); break;
+          default: break;
+        }
+      }
+      if (done) return cf_check_launch("cf_conv3x3_f16x3");
+    }
+  }
   const bool big = (long)a->H * a->W >= 4096;     // (never a function of the batch size: WK changes the
                                                   //  summation order, and a shard of a batch has to
                                                   //  reproduce the full batch bit for bit)

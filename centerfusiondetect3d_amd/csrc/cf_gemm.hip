@@ -463,12 +463,8 @@ struct TileCfg {
 // dynamic-LDS limit once per instantiation; 160 KiB per workgroup are available on gfx950).
 template <typename K, typename A>
 void launch_dyn(K kernel, int blocks, size_t dyn, hipStream_t st, const A& args) {
-  static size_t limit = 0;  // one per template instantiation
-  if (dyn > limit) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(dyn < 32768 ? 32768 : dyn));
-    limit = dyn < 32768 ? 32768 : dyn;
-  }
+  static CfLdsLimit lds_limit;  // one per template instantiation
+  lds_limit.ensure(kernel, dyn, 32768);
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), dyn, st, args);
 }
 

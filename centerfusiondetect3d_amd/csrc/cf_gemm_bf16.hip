@@ -295,12 +295,11 @@ extern "C" int cf_conv2d_bf16x3(const cf_conv_args* a, void* stream) {
   if (a->N_pad % 128 == 0) {
     k.NT = a->N_pad / 128;
     if (bk64) {
-      static bool once = false;
-      if (!once) {
+      static std::once_flag once;
+      std::call_once(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_kernel<128, 128, 2, 2, 64>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-        once = true;
-      }
+      });
       hipLaunchKernelGGL((conv_bf16x3_kernel<128, 128, 2, 2, 64>), dim3(MT * k.NT), dim3(256), 0, st, k);
     } else {
       hipLaunchKernelGGL((conv_bf16x3_kernel<128, 128, 2, 2, 32>), dim3(MT * k.NT), dim3(256), 0, st, k);

@@ -521,12 +521,8 @@ int dcn_k_split(int H, int W, int n_chunks, int n_pad) {
 
 template <typename K, typename A>
 void launch_f16(K kernel, dim3 grid, size_t dyn, hipStream_t st, const A& args) {
-  static size_t limit = 0;
-  if (dyn > limit) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(dyn < 16384 ? 16384 : dyn));
-    limit = dyn < 16384 ? 16384 : dyn;
-  }
+  static CfLdsLimit lds_limit;  // one per template instantiation
+  lds_limit.ensure(kernel, dyn, 16384);
   hipLaunchKernelGGL(kernel, grid, dim3(256), dyn, st, args);
 }
 

@@ -15,6 +15,7 @@
 //   * the accumulator has pixels on lanes, so the final NCHW store is coalesced along pixels.
 // Wave w of the 4 owns output channels [64w, 64w+64) x all 64 pixels (2x2 32x32 accumulators); in
 // the output layer the 4 waves split K instead and their partial sums are reduced through LDS.
+#include <stdlib.h>
 #include "cf_common.h"
 
 namespace {
@@ -467,6 +468,7 @@ struct HeadPatchK {
   const unsigned char* src[2];
   int src_c[2];
   int H, W, tiles_x, tiles_y, n_ks;
+  int group;                                 // 0: head-major grid; g > 0: tile-major within groups of g heads
   const unsigned char* w_first[CF_MAX_HEADS];
   const float* b_first[CF_MAX_HEADS];
   const unsigned char* w_out_perm[CF_MAX_HEADS];
@@ -482,8 +484,24 @@ __global__ __launch_bounds__(256, 2) void head_patch_kernel(HeadPatchK q) {
   const int li = lane & 31, h = lane >> 5;
   const int per_img = q.tiles_x * q.tiles_y;
   const int per_head = per_img * (p.M / p.HW);
-  const int head = blockIdx.x / per_head;
-  int rem = blockIdx.x - head * per_head;
+  int head, rem;
+  if (q.group == 0) {                        // head-major: every tile of head 0, then head 1, ...
+    head = blockIdx.x / per_head;
+    rem = blockIdx.x - head * per_head;
+  } else {
+    // tile-major inside groups of `group` heads, XCD-aware: the hardware deals workgroups round-robin over the 8
+    // XCDs, so the blocks one XCD sees (b, b + 8, ...) are made to walk (tile, head of the group) with the head
+    // fastest - the heads of a tile then run back to back on ONE XCD and all but the first find the patch in L2
+    const int g = q.group;
+    const int n_groups = (p.n_heads + g - 1) / g;
+    const int per_group = per_head * g;      // (the last group may be short: its surplus blocks exit)
+    const int grp = blockIdx.x / per_group;
+    const int lb = cf_xcd_remap(blockIdx.x - grp * per_group, per_group);
+    (void)n_groups;
+    rem = lb / g;
+    head = grp * g + (lb - rem * g);
+    if (head >= p.n_heads) return;
+  }
   const int b = rem / per_img;
   rem -= b * per_img;
   const int y0 = (rem / q.tiles_x) * HP_TH, x0 = (rem % q.tiles_x) * HP_TW;
@@ -720,12 +738,8 @@ extern "C" int cf_head_tail(const cf_head_tail_args* a, void* stream) {
   HeadTailK k{};
   const int rc = fill_tail(a, k, "cf_head_tail", true);
   if (rc != CF_OK) return rc;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_tail_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, HT_LDS);
-    attr_set = true;
-  }
+  static CfLdsLimit lds_limit;
+  lds_limit.ensure(head_tail_kernel, HT_LDS, HT_LDS);
   const int tiles = (k.M + HT_PX - 1) / HT_PX;
   hipLaunchKernelGGL(head_tail_kernel, dim3(tiles * a->n_heads), dim3(256), HT_LDS, (hipStream_t)stream, k);
   return cf_check_launch("cf_head_tail");
@@ -770,28 +784,28 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
       hp.b_first[i] = k.b_first[i];
       hp.w_out_perm[i] = reinterpret_cast<const unsigned char*>(a->w_out_perm[i]);
     }
-    const long blocks = (long)hp.tiles_x * hp.tiles_y * a->tail.B * a->tail.n_heads;
-    CF_REQUIRE(blocks < (1L << 31), "cf_head_fused: grid too large");
-    static bool patch_attr = false;
-    if (!patch_attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_patch_kernel<4, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, HP_LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_patch_kernel<4, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, HP_LDS);
-      patch_attr = true;
+    {
+      // grid order: head-major (0).  Measured alternatives (CF_HEAD_GROUP = g, dev tools only): tile-major over all heads
+      // of the launch takes the same time but 2.2x the fabric fetches - the 7 heads' first-layer weights (4.1 MB) no
+      // longer fit an XCD's 4 MB L2 next to the patches; groups of 2 or 4 heads run 3-4 % slower
+      const char* e = getenv("CF_HEAD_GROUP");
+      hp.group = e ? atoi(e) : 0;
+      if (hp.group < 0 || hp.group > a->tail.n_heads) hp.group = 0;
     }
+    const int n_groups = hp.group ? (a->tail.n_heads + hp.group - 1) / hp.group : 1;
+    const long blocks = (long)hp.tiles_x * hp.tiles_y * a->tail.B * (hp.group ? (long)n_groups * hp.group : a->tail.n_heads);
+    CF_REQUIRE(blocks < (1L << 31), "cf_head_fused: grid too large");
+    static CfLdsLimit lim_plain, lim_pc;
+    lim_plain.ensure(head_patch_kernel<4, false>, HP_LDS, HP_LDS);
+    lim_pc.ensure(head_patch_kernel<4, true>, HP_LDS, HP_LDS);
     if (a->n_src == 2)
       hipLaunchKernelGGL((head_patch_kernel<4, true>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
     else
       hipLaunchKernelGGL((head_patch_kernel<4, false>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
     return cf_check_launch("cf_head_fused");
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_fused_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, HF_LDS);
-    attr_set = true;
-  }
+  static CfLdsLimit lds_limit;
+  lds_limit.ensure(head_fused_kernel, HF_LDS, HF_LDS);
   const int tiles = (k.t.M + HT_PX - 1) / HT_PX;
   hipLaunchKernelGGL(head_fused_kernel, dim3(tiles * a->tail.n_heads), dim3(256), HF_LDS, (hipStream_t)stream, k);
   return cf_check_launch("cf_head_fused");

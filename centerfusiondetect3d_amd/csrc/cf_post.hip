@@ -1025,8 +1025,8 @@ extern "C" int cf_pillar_expand(const double* pc_2d, const double* pc_3d, const 
   if ((long)band_rows * W > max_cells) band_rows = max_cells / W;
   CF_REQUIRE(band_rows >= 1, "cf_pillar_expand: W=%d too wide", W);
   const size_t lds = (size_t)band_rows * W * sizeof(int);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pillar_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static CfLdsLimit lds_limit;
+  lds_limit.ensure(pillar_kernel, lds, 65536);
   hipLaunchKernelGGL(pillar_kernel, dim3(B), dim3(PL_THREADS), lds, (hipStream_t)stream, pc_2d, pc_3d, counts,
                      max_n, n_rows, calib, trans, H, W, pillar_h, pillar_w, pillar_l, pc_dep, keep_mask, xy_out,
                      band_rows);

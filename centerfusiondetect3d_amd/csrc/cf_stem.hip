@@ -305,11 +305,8 @@ extern "C" int cf_stem_fused(const cf_stem_args* a, void* stream) {
   k.tiles_y = (a->H / 2 + ST_T1 - 1) / ST_T1;
   const long blocks = (long)k.tiles_x * k.tiles_y * a->B;
   CF_REQUIRE(blocks < (1L << 31) && (long)a->B * a->C * a->H * a->W < (1L << 40), "cf_stem_fused: tensor too large");
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(stem_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
-    attr = true;
-  }
+  static CfLdsLimit lds_limit;
+  lds_limit.ensure(stem_kernel, ST_LDS, ST_LDS);
   hipLaunchKernelGGL(stem_kernel, dim3((unsigned)blocks), dim3(256), ST_LDS, (hipStream_t)stream, k);
   return cf_check_launch("cf_stem_fused");
 }

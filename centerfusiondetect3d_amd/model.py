@@ -16,6 +16,7 @@ sync, hipGraph-capturable).  There is no CPU fallback: without libcfhip.so / a G
 """
 import ctypes as C
 import math
+import threading
 from typing import Dict, List
 
 import torch
@@ -153,8 +154,13 @@ def _param_spec(config) -> List[tuple]:
 class _Plan:
     """Buffers + pre-built launch list for one (B, H, W, device)."""
 
-    def __init__(self, model: "DLASeg", B, H, W, device):
+    def __init__(self, model: "DLASeg", B, H, W, device, part="all", feat=None, feat_in=None):
+        """part: "all" (one plan per forward), or the two halves of the split forward (DLASeg.streams > 1):
+        "trunk" = backbone + neck of a sub-batch, its last DCN writing the feature map (and its split-bf16 copy)
+        into the caller's `feat` / `feat_in` slices; "heads" = everything behind the feature map for the WHOLE
+        batch, reading the full `feat` / `feat_in` buffers the trunks filled."""
         self.B, self.H, self.W, self.device = B, H, W, device
+        self.part = part
         self.lib = _lib.load()
         self.steps = []          # (fn, args...) tuples executed in order (stream appended at run)
         self.keep = []           # keeps arg blocks / buffers alive
@@ -231,12 +237,12 @@ class _Plan:
             children.append(x1)
             return tree(p + ".tree2", levels - 1, x1, 1, False, children)
 
-        def dcn_node(p, x):
+        def dcn_node(p, x, out=None):
             _, h, w, c = x.shape
             om = buf(B, h, w, 32)
             conv(p + ".conv_offset_mask", [x], h, w, act=ACT_NONE, out=om, out_stride=32)
             pd = pk[p]
-            o = buf(B, h, w, pd.n)
+            o = buf(B, h, w, pd.n) if out is None else out
             ws = None
             if pd.out_scale > 0:
                 nbytes = self.lib.cf_dcn_v2_workspace_bytes(B, h, w, pd.c, pd.n_pad)
@@ -248,7 +254,7 @@ class _Plan:
             self.steps.append((self.lib.cf_dcn_v2_f16x3 if pd.out_scale > 0 else self.lib.cf_dcn_v2_fused, C.byref(a)))
             return o
 
-        def ida(p, layers, startp, endp):
+        def ida(p, layers, startp, endp, final_out=None):
             for i in range(startp + 1, endp):
                 j = i - startp
                 proj = dcn_node(f"{p}.proj_{j}", layers[i])
@@ -257,51 +263,71 @@ class _Plan:
                 summed = buf(B, h * f, w * f, c)          # up(proj(x)) + skip, fused
                 self.steps.append((self.lib.cf_upsample_dw, proj.data_ptr(), wk.data_ptr(),
                                    layers[i - 1].data_ptr(), summed.data_ptr(), B, h, w, c, f))
-                layers[i] = dcn_node(f"{p}.node_{j}", summed)
+                layers[i] = dcn_node(f"{p}.node_{j}", summed, out=final_out if i == endp - 1 else None)
 
-        # ---- backbone
-        self.in_step = len(self.steps)
-        self.steps.append(None)                            # first step reads the images: patched per call
-        self.stem = None
-        if "base.stem" in pk:
-            # base_layer + level0 + level1 in one launch; the full-resolution maps stay in LDS
-            y0, y1 = None, buf(B, H // 2, W // 2, 32)
-            self.stem = ops.stem_args(pk["base.stem"], None, y1, shape=(B, 3, H, W))
-            self.keep.append(self.stem)
-            self.step_index["base.stem"] = self.in_step
-            self.step_flops["base.stem"] = 2.0 * B * H * W * (16 * 147 + 16 * 144 + 32 * 144 / 4)
-        else:
-            self.x4 = buf(B, H, W, 4)
-            t, _ = conv("base.base_layer", [self.x4], H, W)
-            y0, _ = conv("base.level0", [t], H, W)
-            y1, _ = conv("base.level1", [y0], H, W)
-        layers = [y0, y1]
-        x = y1
-        for lvl, levels, root in ((2, 1, False), (3, 2, True), (4, 2, True), (5, 1, True)):
-            x = tree(f"base.level{lvl}", levels, x, 2, root)
-            layers.append(x)
-        self.debug = {f"y{i}": t for i, t in enumerate(layers) if t is not None}   # NHWC stage outputs (tests only)
-        # ---- DLA-up + IDA-up neck
-        out = [layers[-1]]
-        for i in range(len(layers) - 2 - 1):
-            ida(f"dla_up.ida_{i}", layers, len(layers) - i - 2, len(layers))
-            out.insert(0, layers[-1])
-        for i, t in enumerate(out):
-            self.debug[f"up{i}"] = t
-        y = out[:3]
-        ida("ida_up", y, 0, 3)
-        feat = y[-1]
-        self.feat = feat
-        _, h4, w4, _ = feat.shape
+        bf = bool(model.heads_bf16)                        # split-bf16 ("bf16x3") head GEMMs
+        h4, w4 = H // 4, W // 4
         self.h4, self.w4 = h4, w4
+        self.in_step = None
+        self.stem = None
+        self.debug = {}
+        if part != "heads":
+            # ---- backbone
+            self.in_step = len(self.steps)
+            self.steps.append(None)                            # first step reads the images: patched per call
+            if "base.stem" in pk:
+                # base_layer + level0 + level1 in one launch; the full-resolution maps stay in LDS
+                y0, y1 = None, buf(B, H // 2, W // 2, 32)
+                self.stem = ops.stem_args(pk["base.stem"], None, y1, shape=(B, 3, H, W))
+                self.keep.append(self.stem)
+                self.step_index["base.stem"] = self.in_step
+                self.step_flops["base.stem"] = 2.0 * B * H * W * (16 * 147 + 16 * 144 + 32 * 144 / 4)
+            else:
+                self.x4 = buf(B, H, W, 4)
+                t, _ = conv("base.base_layer", [self.x4], H, W)
+                y0, _ = conv("base.level0", [t], H, W)
+                y1, _ = conv("base.level1", [y0], H, W)
+            layers = [y0, y1]
+            x = y1
+            for lvl, levels, root in ((2, 1, False), (3, 2, True), (4, 2, True), (5, 1, True)):
+                x = tree(f"base.level{lvl}", levels, x, 2, root)
+                layers.append(x)
+            self.debug = {f"y{i}": t for i, t in enumerate(layers) if t is not None}   # NHWC stage outputs (tests only)
+            # ---- DLA-up + IDA-up neck
+            out = [layers[-1]]
+            for i in range(len(layers) - 2 - 1):
+                ida(f"dla_up.ida_{i}", layers, len(layers) - i - 2, len(layers))
+                out.insert(0, layers[-1])
+            for i, t in enumerate(out):
+                self.debug[f"up{i}"] = t
+            y = out[:3]
+            ida("ida_up", y, 0, 3, final_out=feat)
+            feat = y[-1]
+            if bf:
+                # the split-bf16 copy of the feature map the heads read is written by the epilogue of the DCN
+                # that produces it (f16x3 kernel); a separate split pass only if that kernel is not in use
+                if feat_in is None:
+                    feat_in = buf(B, h4, w4, 2, 64, dtype=torch.bfloat16)
+                producer = [a for a in self.keep if isinstance(a, _lib.DcnArgs) and a.out == feat.data_ptr()
+                            and a.out_scale > 0 and a.N == 64]
+                if producer:
+                    producer[-1].out_split_bf16, producer[-1].split_stride = feat_in.data_ptr(), 64
+                    producer[-1].workspace = None          # (the split output and a K-split reduction exclude each other)
+                else:
+                    self.steps.append((self.lib.cf_split_bf16, feat.data_ptr(), feat_in.data_ptr(), B * h4 * w4, 64, 64, 64))
+            else:
+                feat_in = feat
+        self.feat, self.feat_in = feat, feat_in
+        self.primary, self.radar, self.K = [], False, K
+        self.outs: Dict[str, List] = {}
+        self.tails = {}
+        if part == "trunk":
+            return
 
         # ---- heads.  Per-call output tensors are patched into these arg blocks (self.outs).
-        self.outs: Dict[str, List] = {}                    # head -> argblock
         primary = [h for h in heads if not (radar and h in SECONDARY_HEADS)]
         self.primary = primary
         self.radar = radar
-        self.K = K
-        bf = bool(model.heads_bf16)                        # split-bf16 ("bf16x3") head GEMMs
         M4 = B * h4 * w4
 
         def hconv(name, srcs, strides, out_c=None, out=None, out_offset=0, act=ACT_RELU):
@@ -331,19 +357,6 @@ class _Plan:
             self.steps.append((self.lib.cf_conv2d_bf16x3 if bf else self.lib.cf_conv2d_fused, C.byref(a)))
             self.outs[h] = a
 
-        if bf:
-            feat_in = buf(B, h4, w4, 2, 64, dtype=torch.bfloat16)
-            # the split-bf16 copy of the feature map the heads read is written by the epilogue of the DCN
-            # that produces it (f16x3 kernel); a separate split pass only if that kernel is not in use
-            producer = [a for a in self.keep if isinstance(a, _lib.DcnArgs) and a.out == feat.data_ptr()
-                        and a.out_scale > 0 and a.N == 64]
-            if producer:
-                producer[-1].out_split_bf16, producer[-1].split_stride = feat_in.data_ptr(), 64
-                producer[-1].workspace = None          # (the split output and a K-split reduction exclude each other)
-            else:
-                self.steps.append((self.lib.cf_split_bf16, feat.data_ptr(), feat_in.data_ptr(), M4, 64, 64, 64))
-        else:
-            feat_in = feat
         hs = 256 * len(primary)
         hid = None if (bf and model.heads_fused) else hconv("heads.primary.0", [feat_in], [64], out_c=hs)
 
@@ -376,7 +389,6 @@ class _Plan:
                 for h, d in zip(names, hd))
             self.steps.append((self.lib.cf_head_fused, C.byref(f)))
 
-        self.tails = {}
         fuse_all = bf and bool(model.heads_fused)
         if fuse_all:
             fused_heads("tails.primary", primary, [feat_in], [64])
@@ -410,9 +422,38 @@ class _Plan:
                     head_out(h, s1, ss)
 
     # ------------------------------------------------------------------------------------------
+    def _launch(self, st):
+        if self.timed:
+            for i, step in enumerate(self.steps):
+                ev = self.timed.get(i)
+                if ev is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                rc = step[0](*step[1:], st)
+                if ev is not None:
+                    e1.record()
+                    ev.append((e0, e1))
+                if rc != 0:
+                    _lib.check(rc, step[0].__name__)
+            return
+        for step in self.steps:
+            rc = step[0](*step[1:], st)
+            if rc != 0:
+                _lib.check(rc, step[0].__name__)
+
+    def run_trunk(self, x):
+        """part == "trunk": images of this sub-batch -> its slice of the shared feature buffers (current stream)."""
+        lib = self.lib
+        if self.stem is not None:
+            self.stem.x = x.data_ptr()
+            self.steps[self.in_step] = (lib.cf_stem_fused, C.byref(self.stem))
+        else:
+            self.steps[self.in_step] = (lib.cf_nchw_to_nhwc4, x.data_ptr(), self.x4.data_ptr(), self.B, 3, self.H, self.W)
+        self._launch(_lib.stream_ptr())
+
     def run(self, model, x, pc_dep, calib, alloc=None):
-        """alloc(c): where a (B, c, h4, w4) output goes (default: a fresh tensor) - the two-stream
-        forward hands out batch slices of full-batch tensors here."""
+        """alloc(c): where a (B, c, h4, w4) output goes (default: a fresh tensor).  part == "heads": `x` is unused
+        (the feature buffers were filled by the trunk plans)."""
         B, H, W, dev = self.B, self.H, self.W, self.device
         lib = self.lib
         st = _lib.stream_ptr()
@@ -438,11 +479,12 @@ class _Plan:
         y["depth"] = new(1)
         set_out("depth", y["depth"], second=True)
         y["calib"] = calib
-        if self.stem is not None:
-            self.stem.x = x.data_ptr()
-            self.steps[self.in_step] = (lib.cf_stem_fused, C.byref(self.stem))
-        else:
-            self.steps[self.in_step] = (lib.cf_nchw_to_nhwc4, x.data_ptr(), self.x4.data_ptr(), B, 3, H, W)
+        if self.in_step is not None:
+            if self.stem is not None:
+                self.stem.x = x.data_ptr()
+                self.steps[self.in_step] = (lib.cf_stem_fused, C.byref(self.stem))
+            else:
+                self.steps[self.in_step] = (lib.cf_nchw_to_nhwc4, x.data_ptr(), self.x4.data_ptr(), B, 3, H, W)
         if self.radar:
             pc_hm = new(3)
             self.steps[self.topk_step] = (lib.cf_topk_peaks, y["heatmap"].data_ptr(), B, heads["heatmap"],
@@ -465,23 +507,7 @@ class _Plan:
             y["depthMap"] = y["depth2"]                    # raw depth2 logits (detectHeads.py:188-190)
             y["depth2"] = new(1)
             set_out("depth2", y["depth2"], second=True)
-        if self.timed:
-            for i, step in enumerate(self.steps):
-                ev = self.timed.get(i)
-                if ev is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                rc = step[0](*step[1:], st)
-                if ev is not None:
-                    e1.record()
-                    ev.append((e0, e1))
-                if rc != 0:
-                    _lib.check(rc, step[0].__name__)
-            return [y]
-        for step in self.steps:
-            rc = step[0](*step[1:], st)
-            if rc != 0:
-                _lib.check(rc, step[0].__name__)
+        self._launch(st)
         return [y]
 
 
@@ -552,9 +578,11 @@ class DLASeg(nn.Module):
             _register(self, name, tensor, is_buf)
         self._packed = None
         self._plans = {}
+        self._lock = threading.RLock()     # plans (buffers + argument blocks) are built / patched / launched under it
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
-        self.streams = 1         # > 1: the batch as that many sub-batches on concurrent HIP streams (own plans)
+        self.streams = 2         # > 1 (and batch >= 4 * streams): backbone + neck as that many sub-batches on
+                                 # concurrent HIP streams with their own plans; heads on the caller's stream
         self._stream_pool = {}
         self.use_graph = False   # replay the forward as ONE captured HIP graph (inputs / outputs staged through
                                  # static buffers) instead of ~90 launches from Python.  Measured: no gain - the
@@ -714,75 +742,72 @@ class DLASeg(nn.Module):
             if pc_dep.dtype != torch.float32 or not pc_dep.is_contiguous():
                 raise ValueError("pc_dep must be contiguous float32")
             calib = calib.reshape(B, 3, 4).float().contiguous()
-        if self._packed is None:
-            self._prepare(dev)
-        if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 4 and not self.use_graph:
-            with torch.cuda.device(dev):
-                return self._forward_concurrent(x, pc_dep, calib, B, H, W, dev)
-        key = (B, H, W, dev)
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = self._plans[key] = _Plan(self, B, H, W, dev)
-        with torch.cuda.device(dev):
+        # One model may be driven from several HIP streams and host threads.  A plan owns its intermediate buffers, so
+        # plans are keyed by the stream the call is issued on (two forwards in flight on two streams never share a
+        # buffer); building, patching the per-call pointers into the argument blocks and issuing the launches happen
+        # under the model's lock (kernel arguments are copied at launch, so the blocks are free again on return).
+        with self._lock, torch.cuda.device(dev):
+            if self._packed is None:
+                self._prepare(dev)
+            sid = torch.cuda.current_stream(dev).cuda_stream
+            if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 4 and not self.use_graph:
+                return self._forward_concurrent(x, pc_dep, calib, B, H, W, dev, sid)
+            key = (B, H, W, dev, sid)
+            plan = self._plans.get(key)
+            if plan is None:
+                plan = self._plans[key] = _Plan(self, B, H, W, dev)
             if self.use_graph:
                 return plan.replay(self, x, pc_dep, calib)
             return plan.run(self, x, pc_dep, calib)
 
-    def _forward_concurrent(self, x, pc_dep, calib, B, H, W, dev):
-        """The batch as `self.streams` sub-batches, each with its OWN plan (own intermediate buffers) on
-        its OWN HIP stream: several layers cannot fill the chip on their own (level4: 175 workgroups for
-        256 CUs, the 14x25 / 28x50 maps of the neck, the tail round of most grids) and the other
-        sub-batch's launches fill those holes.  Frames are independent, so the result is the single-stream
-        one bit for bit; outputs are batch slices of full-batch tensors (no concatenation)."""
+    def _forward_concurrent(self, x, pc_dep, calib, B, H, W, dev, sid):
+        """Backbone + neck as `self.streams` sub-batches, each with its OWN trunk plan (own intermediate buffers)
+        on its OWN HIP stream: several of those layers cannot fill the chip on their own (level4: 175 workgroups
+        for 256 CUs, the 14x25 / 28x50 maps of the neck, the tail round of most grids) and the other sub-batch's
+        launches fill the holes.  The trunks write their slices of ONE full-batch feature map; the heads, top-k,
+        frustum association and secondary heads then run for the whole batch on the caller's stream (their grids
+        fill the chip, and a launch there overlaps nothing - HIP-event and rocprofv3 durations of the head kernels
+        mean the same thing as in the single-stream forward).  Frames are independent, so the result is the
+        single-stream one bit for bit."""
         n = self.streams
         k = B // n
         h4, w4 = H // 4, W // 4
         cur = torch.cuda.current_stream(dev)
-        pool = self._stream_pool.setdefault(dev, [])
+        pool = self._stream_pool.setdefault((dev, sid), [])
         while len(pool) < n:
             pool.append(torch.cuda.Stream(dev))
         pool = pool[:n]
-        full, ys = [], []
+        hkey = (B, H, W, dev, sid, "heads")
+        hplan = self._plans.get(hkey)
+        bf = bool(self.heads_bf16)
+        if hplan is None:
+            feat = torch.empty((B, h4, w4, 64), device=dev, dtype=torch.float32)
+            feat_in = torch.empty((B, h4, w4, 2, 64), device=dev, dtype=torch.bfloat16) if bf else feat
+            hplan = self._plans[hkey] = _Plan(self, B, H, W, dev, part="heads", feat=feat, feat_in=feat_in)
         for i in range(n):
-            key = (k, H, W, dev, i)
-            plan = self._plans.get(key)
-            if plan is None:
-                plan = self._plans[key] = _Plan(self, k, H, W, dev)
-            count = [0]
-
-            def alloc(c, i=i, count=count):
-                j = count[0]
-                count[0] += 1
-                if i == 0:
-                    full.append(torch.empty((B, c, h4, w4), device=dev, dtype=torch.float32))
-                return full[j][i * k:(i + 1) * k]
-
-            sl = slice(i * k, (i + 1) * k)
+            tkey = (B, k, H, W, dev, sid, "trunk", i)
+            tplan = self._plans.get(tkey)
+            if tplan is None:
+                sl = slice(i * k, (i + 1) * k)
+                tplan = self._plans[tkey] = _Plan(self, k, H, W, dev, part="trunk", feat=hplan.feat[sl],
+                                                  feat_in=hplan.feat_in[sl] if bf else None)
             s = pool[i]
             s.wait_stream(cur)
             with torch.cuda.stream(s):
-                ys.append(plan.run(self, x[sl], pc_dep[sl] if pc_dep is not None else None,
-                                   calib[sl] if calib is not None else None, alloc=alloc)[0])
+                tplan.run_trunk(x[i * k:(i + 1) * k])
         for s in pool:
             cur.wait_stream(s)
-        y = {}
-        for key_, v in ys[0].items():
-            if key_ == "calib":
-                y[key_] = calib
-            elif key_ == "pc_hm_in":
-                y[key_] = pc_dep[:, :1]
-            else:      # a batch slice (or a view of one) of a full tensor -> the same view over the whole batch
-                base = v._base if v._base is not None else v
-                y[key_] = torch.as_strided(base, (B,) + tuple(v.shape[1:]), v.stride(), v.storage_offset())
-        return [y]
+        return hplan.run(self, None, pc_dep, calib)
 
 
     # ------------------------------------------------------------------------- instrumentation
     def time_launch(self, name, on=True):
-        """Bracket the named conv launch with HIP events (recorded on the launch stream) in every
-        existing plan; read back with launch_times().  Names: 'heads.primary.0', 'base.level0', ..."""
+        """Bracket the named launch with HIP events (recorded on the launch stream) in every existing plan that
+        holds it; read back with launch_times().  Names: 'tails.primary', 'base.level2.root', ..."""
         for plan in self._plans.values():
-            idx = plan.step_index[name]
+            idx = plan.step_index.get(name)
+            if idx is None:
+                continue
             if on:
                 plan.timed.setdefault(idx, [])
             else:
@@ -793,7 +818,9 @@ class DLASeg(nn.Module):
         torch.cuda.synchronize()
         out, flops = [], 0.0
         for plan in self._plans.values():
-            idx = plan.step_index[name]
+            idx = plan.step_index.get(name)
+            if idx is None:
+                continue
             flops = plan.step_flops[name]
             for e0, e1 in plan.timed.get(idx, []):
                 out.append(e0.elapsed_time(e1))
@@ -807,7 +834,7 @@ class DLASeg(nn.Module):
             plan.timed = {i: [] for i in range(len(plan.steps))} if on else {}
 
     def all_launch_times(self):
-        """-> [(step name or kernel entry point, mean ms, algorithmic FLOPs)] in launch order."""
+        """-> [(step name or kernel entry point, mean ms, algorithmic FLOPs)] in launch order (single-plan forward)."""
         torch.cuda.synchronize()
         plan = list(self._plans.values())[-1]
         names = {v: k for k, v in plan.step_index.items()}
@@ -822,9 +849,8 @@ class DLASeg(nn.Module):
         return out
 
     def conv_flops_per_forward(self):
-        """Algorithmic FLOPs (2*MACs) of all conv / DCN launches of the newest plan."""
-        plan = list(self._plans.values())[-1]
-        return sum(plan.step_flops.values())
+        """Algorithmic FLOPs (2*MACs) of all conv / DCN launches of one forward (the plans in use)."""
+        return sum(sum(p.step_flops.values()) for p in self._plans.values())
 
 
 _network_factory = {"dla": DLASeg}

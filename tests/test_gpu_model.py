@@ -374,29 +374,43 @@ def test_graph_replay_equals_eager(dev, radar, B):
 
 
 def test_two_stream_forward_equals_single_stream(dev):
-    """model.streams = 2: the batch as two sub-batches with their own plans on concurrent HIP streams -
-    bit for bit the single-stream result (also on repetition: no buffer is shared between the streams),
-    full-batch output tensors, views and aliases as in the single-stream dict."""
+    """model.streams = 2 (the default for batches >= 8): backbone + neck as two sub-batches with their own plans on
+    concurrent HIP streams, heads for the whole batch on the caller's stream - bit for bit the single-stream result
+    (also on repetition: no buffer is shared between the streams), views and aliases as in the single-stream dict;
+    streams = 4 and a camera-only model likewise."""
     from centerfusiondetect3d_amd import decode_packed
     H, W, B = 448, 800, 16
     m = _model(True, dev, (H, W))
+    assert m.streams == 2
     x, pc_dep, calib = cases.model_inputs(B, H, W, seed=45, radar=True, n_points=(50, 200))
     xd, pd, cd = x.to(dev), pc_dep.to(dev), calib.to(dev)
     with torch.no_grad():
+        m.streams = 1
         one = m(xd, pc_dep=pd, calib=cd)
         det1, _ = decode_packed([dict(one[0])], (112, 200), 100)     # (decode renames rotation2 in the dict it gets)
-        m.streams = 2
-        for rep in range(4):
-            two = m(xd, pc_dep=pd, calib=cd)
-            assert list(two[0].keys()) == list(one[0].keys())
-            for k in one[0]:
-                assert two[0][k].shape == one[0][k].shape, k
-                assert torch.equal(two[0][k], one[0][k]), (rep, k)
-            det2, _ = decode_packed([dict(two[0])], (112, 200), 100)
-            assert torch.equal(det1, det2)
-        assert two[0]["pc_hm_in"].data_ptr() == pd.data_ptr()
-        assert two[0]["pc_hm"].data_ptr() == two[0]["pc_hm_out"].data_ptr()
-        m.streams = 1
+        for n_streams in (2, 4):
+            m.streams = n_streams
+            for rep in range(3):
+                two = m(xd, pc_dep=pd, calib=cd)
+                assert list(two[0].keys()) == list(one[0].keys())
+                for k in one[0]:
+                    assert two[0][k].shape == one[0][k].shape, k
+                    assert torch.equal(two[0][k], one[0][k]), (n_streams, rep, k)
+                det2, _ = decode_packed([dict(two[0])], (112, 200), 100)
+                assert torch.equal(det1, det2)
+            assert two[0]["pc_hm_in"].data_ptr() == pd.data_ptr()
+            assert two[0]["pc_hm"].data_ptr() == two[0]["pc_hm_out"].data_ptr()
+        assert any(isinstance(k, tuple) and "trunk" in k for k in m._plans)     # the split path really ran
+    mc = _model(False, dev, (256, 416))
+    xc = cases.model_inputs(8, 256, 416, seed=46, radar=False)[0].to(dev)
+    with torch.no_grad():
+        mc.streams = 1
+        a = mc(xc)[0]
+        mc.streams = 2
+        b = mc(xc)[0]
+    for k in a:
+        if k != "calib":
+            assert torch.equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("tag,radar,B,H,W", [("centerfusion_small", True, 2, 128, 160),
@@ -427,3 +441,42 @@ def test_stage_buffers_match_reference_submodules(dev, golden_dir, tag, radar, B
         print(f"[stage] {n:>5s}: max|err|/max|ref| = {err.max() / scale:.2e}")
         checked += 1
     assert checked == 10
+
+
+def test_one_model_two_streams_two_threads(dev):
+    """Re-entrancy (SURVEY §8(b) "re-entrant per stream"): one model driven from two HIP streams, by two host
+    threads at once - each stream gets its own plan (own intermediate buffers), so forwards in flight on different
+    streams never share memory; results equal the sequential ones bit for bit."""
+    import threading
+    H, W, B = 128, 160, 2
+    m = _model(True, dev, (H, W))
+    ins = []
+    for seed in (61, 62):
+        x, pc_dep, calib = cases.model_inputs(B, H, W, seed=seed, radar=True)
+        ins.append((x.to(dev), pc_dep.to(dev), calib.to(dev)))
+    with torch.no_grad():
+        want = [{k: v.clone() for k, v in m(a, pc_dep=b, calib=c)[0].items()} for a, b, c in ins]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    got = [None, None]
+    errs = []
+
+    def work(i):
+        try:
+            with torch.no_grad(), torch.cuda.stream(streams[i]):
+                for _ in range(6):                                   # several forwards in flight per stream
+                    got[i] = m(ins[i][0], pc_dep=ins[i][1], calib=ins[i][2])[0]
+        except Exception as e:                                        # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(2):
+        for k, v in want[i].items():
+            if k != "calib":
+                assert torch.equal(got[i][k], v), (i, k)
+    sids = {k[4] for k in m._plans if isinstance(k, tuple) and len(k) == 5}
+    assert len(sids) >= 3                                             # default stream + the two side streams

@@ -19,6 +19,7 @@ m = getModel(centerfusion_middle_config((H, W)))
 m.heads_bf16 = not a.fp32_heads
 m.precise = not a.no_precise
 m.conv_f16 = not a.fp32_convs
+m.streams = 1          # per-launch event timing needs one stream
 m = bench.synthetic_weights(m).to(dev).eval()
 images, pc_dep, calib = bench.make_inputs(a.batch, H, W, dev, 1000)
 with torch.no_grad():
