@@ -163,6 +163,12 @@ class _Plan:
         self.part = part
         self.lib = _lib.load()
         self.steps = []          # (fn, args...) tuples executed in order (stream appended at run)
+        self.lanes = []          # per step: 0 = the caller's stream, 1 = the plan's side stream (see ida())
+        self.lane = 0
+        self.n_events = 0
+        # two-lane issue of the neck for small batches (a launch cannot fill the chip there); never with the timed /
+        # graph paths, which want one stream
+        self.use_lanes = bool(model.lanes) and part != "heads" and B * (H // 4) * (W // 4) <= 4 * 112 * 200
         self.keep = []           # keeps arg blocks / buffers alive
         self.bytes = 0
         self.step_index = {}     # conv name -> index in self.steps
@@ -201,13 +207,13 @@ class _Plan:
             fn = self.lib.cf_conv2d_fused
             if pc.out_scale > 0:
                 fn = self.lib.cf_conv3x3_f16x3 if (pc.patch and model.conv_patch) else self.lib.cf_conv2d_f16x3
-            self.steps.append((fn, C.byref(a)))
+            self.add_step((fn, C.byref(a)))
             return out, a
 
         def pool(x):
             _, h, w, c = x.shape
             o = buf(B, h // 2, w // 2, c)
-            self.steps.append((self.lib.cf_maxpool2x2, x.data_ptr(), o.data_ptr(), B, h, w, c))
+            self.add_step((self.lib.cf_maxpool2x2, x.data_ptr(), o.data_ptr(), B, h, w, c))
             return o
 
         def block(p, x, residual):
@@ -251,18 +257,37 @@ class _Plan:
             self.keep.append(a)
             self.step_index[p] = len(self.steps)
             self.step_flops[p] = 2.0 * B * h * w * pd.n * 9 * pd.c
-            self.steps.append((self.lib.cf_dcn_v2_f16x3 if pd.out_scale > 0 else self.lib.cf_dcn_v2_fused, C.byref(a)))
+            self.add_step((self.lib.cf_dcn_v2_f16x3 if pd.out_scale > 0 else self.lib.cf_dcn_v2_fused, C.byref(a)))
             return o
 
         def ida(p, layers, startp, endp, final_out=None):
+            """IDAUp.forward (dla.py:518-524).  The projections of one IDA level read maps that all exist when the level
+            starts and do not depend on each other or on the nodes, so with `self.use_lanes` they are issued on a side
+            stream (offset conv + DCN per projection) while the caller's stream runs the node chain
+            upsample+skip -> offset conv -> DCN, waiting for projection j right before it consumes it.  Small
+            batches only: there a single launch cannot fill the chip and the two chains overlap (bit-identical)."""
+            projs = {}
+            if self.use_lanes:
+                self.ctl("rec", 0, ev0 := self.new_event())      # everything the projections read is complete here
+                self.ctl("wait", 1, ev0)
+                self.lane = 1
+                for i in range(startp + 1, endp):
+                    projs[i] = dcn_node(f"{p}.proj_{i - startp}", layers[i])
+                    self.ctl("rec", 1, ev := self.new_event())
+                    projs[i] = (projs[i], ev)
+                self.lane = 0
             for i in range(startp + 1, endp):
                 j = i - startp
-                proj = dcn_node(f"{p}.proj_{j}", layers[i])
+                if self.use_lanes:
+                    proj, ev = projs[i]
+                    self.ctl("wait", 0, ev)
+                else:
+                    proj = dcn_node(f"{p}.proj_{j}", layers[i])
                 wk, f = pk[f"{p}.up_{j}"]
                 _, h, w, c = proj.shape
                 summed = buf(B, h * f, w * f, c)          # up(proj(x)) + skip, fused
-                self.steps.append((self.lib.cf_upsample_dw, proj.data_ptr(), wk.data_ptr(),
-                                   layers[i - 1].data_ptr(), summed.data_ptr(), B, h, w, c, f))
+                self.add_step((self.lib.cf_upsample_dw, proj.data_ptr(), wk.data_ptr(),
+                               layers[i - 1].data_ptr(), summed.data_ptr(), B, h, w, c, f))
                 layers[i] = dcn_node(f"{p}.node_{j}", summed, out=final_out if i == endp - 1 else None)
 
         bf = bool(model.heads_bf16)                        # split-bf16 ("bf16x3") head GEMMs
@@ -274,7 +299,7 @@ class _Plan:
         if part != "heads":
             # ---- backbone
             self.in_step = len(self.steps)
-            self.steps.append(None)                            # first step reads the images: patched per call
+            self.add_step(None)                            # first step reads the images: patched per call
             if "base.stem" in pk:
                 # base_layer + level0 + level1 in one launch; the full-resolution maps stay in LDS
                 y0, y1 = None, buf(B, H // 2, W // 2, 32)
@@ -314,7 +339,7 @@ class _Plan:
                     producer[-1].out_split_bf16, producer[-1].split_stride = feat_in.data_ptr(), 64
                     producer[-1].workspace = None          # (the split output and a K-split reduction exclude each other)
                 else:
-                    self.steps.append((self.lib.cf_split_bf16, feat.data_ptr(), feat_in.data_ptr(), B * h4 * w4, 64, 64, 64))
+                    self.add_step((self.lib.cf_split_bf16, feat.data_ptr(), feat_in.data_ptr(), B * h4 * w4, 64, 64, 64))
             else:
                 feat_in = feat
         self.feat, self.feat_in = feat, feat_in
@@ -342,7 +367,7 @@ class _Plan:
             self.keep.append(a)
             self.step_index[name] = len(self.steps)
             self.step_flops[name] = 2.0 * M4 * pc.n * (pc.kh * pc.kh * sum(int(c) for c in pc.real_cin))
-            self.steps.append((self.lib.cf_conv2d_bf16x3 if bf else self.lib.cf_conv2d_fused, C.byref(a)))
+            self.add_step((self.lib.cf_conv2d_bf16x3 if bf else self.lib.cf_conv2d_fused, C.byref(a)))
             return out
 
         def head_out(h, src, src_stride):
@@ -354,7 +379,7 @@ class _Plan:
             self.keep.append(a)
             self.step_index[f"heads.{h}.out"] = len(self.steps)
             self.step_flops[f"heads.{h}.out"] = 2.0 * M4 * pc.n * 256
-            self.steps.append((self.lib.cf_conv2d_bf16x3 if bf else self.lib.cf_conv2d_fused, C.byref(a)))
+            self.add_step((self.lib.cf_conv2d_bf16x3 if bf else self.lib.cf_conv2d_fused, C.byref(a)))
             self.outs[h] = a
 
         hs = 256 * len(primary)
@@ -374,7 +399,7 @@ class _Plan:
             self.step_index[name] = len(self.steps)
             self.step_flops[name] = sum(2.0 * M4 * 256 * (256 * len(pk[name][h]["w_hidden"]) + heads[h])
                                         for h in names)
-            self.steps.append((self.lib.cf_head_tail, C.byref(a)))
+            self.add_step((self.lib.cf_head_tail, C.byref(a)))
 
         def fused_heads(name, names, srcs, strides):
             """One cf_head_fused launch: 3x3 + ReLU + tail for sibling heads, hidden never in HBM."""
@@ -387,7 +412,7 @@ class _Plan:
             self.step_flops[name] = sum(
                 2.0 * M4 * 256 * (9 * sum(d["real_cin"]) + 256 * len(d["w_hidden"]) + heads[h])
                 for h, d in zip(names, hd))
-            self.steps.append((self.lib.cf_head_fused, C.byref(f)))
+            self.add_step((self.lib.cf_head_fused, C.byref(f)))
 
         fuse_all = bf and bool(model.heads_fused)
         if fuse_all:
@@ -404,8 +429,8 @@ class _Plan:
             self.pc_hm4 = None if bf else buf(B, h4, w4, 4)
             self.pc_hm8 = buf(B, h4, w4, 2, 8, dtype=torch.bfloat16) if bf else None
             self.tk_ws = buf(max(1, self.lib.cf_topk_workspace_bytes(B, K)), dtype=torch.uint8)
-            self.topk_step = len(self.steps); self.steps.append(None)
-            self.frustum_step = len(self.steps); self.steps.append(None)
+            self.topk_step = len(self.steps); self.add_step(None)
+            self.frustum_step = len(self.steps); self.add_step(None)
             ss = 256 * len(SECONDARY_HEADS)
             if fuse_all:
                 fused_heads("tails.secondary", SECONDARY_HEADS, [feat_in, self.pc_hm8], [64, 8])
@@ -422,9 +447,24 @@ class _Plan:
                     head_out(h, s1, ss)
 
     # ------------------------------------------------------------------------------------------
+    def add_step(self, step):
+        self.steps.append(step)
+        self.lanes.append(self.lane)
+
+    def ctl(self, op, lane, ev):
+        """Cross-lane ordering: ("rec" | "wait", lane, event id)."""
+        self.steps.append((op, ev))
+        self.lanes.append(lane)
+
+    def new_event(self):
+        self.n_events += 1
+        return self.n_events - 1
+
     def _launch(self, st):
         if self.timed:
             for i, step in enumerate(self.steps):
+                if isinstance(step[0], str):
+                    continue                                   # one stream: program order is the dependency order
                 ev = self.timed.get(i)
                 if ev is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -436,10 +476,32 @@ class _Plan:
                 if rc != 0:
                     _lib.check(rc, step[0].__name__)
             return
-        for step in self.steps:
-            rc = step[0](*step[1:], st)
-            if rc != 0:
-                _lib.check(rc, step[0].__name__)
+        if not self.use_lanes or torch.cuda.is_current_stream_capturing():
+            for step in self.steps:
+                if isinstance(step[0], str):
+                    continue
+                rc = step[0](*step[1:], st)
+                if rc != 0:
+                    _lib.check(rc, step[0].__name__)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.device)
+            self._events = [torch.cuda.Event() for _ in range(self.n_events)]
+        streams = (cur, self._side)
+        ptrs = (st, self._side.cuda_stream)
+        for step, lane in zip(self.steps, self.lanes):
+            op = step[0]
+            if op == "rec":
+                self._events[step[1]].record(streams[lane])
+            elif op == "wait":
+                streams[lane].wait_event(self._events[step[1]])
+            else:
+                rc = op(*step[1:], ptrs[lane])
+                if rc != 0:
+                    _lib.check(rc, op.__name__)
+        # (every side-lane launch is waited for by a main-lane step that consumes it: the caller's stream is again
+        #  the only one with work in flight when this returns)
 
     def run_trunk(self, x):
         """part == "trunk": images of this sub-batch -> its slice of the shared feature buffers (current stream)."""
@@ -581,6 +643,7 @@ class DLASeg(nn.Module):
         self._lock = threading.RLock()     # plans (buffers + argument blocks) are built / patched / launched under it
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
+        self.lanes = True        # small batches: the IDA projections on a side stream beside the node chain (_Plan.ida)
         self.streams = 2         # > 1 (and batch >= 4 * streams): backbone + neck as that many sub-batches on
                                  # concurrent HIP streams with their own plans; heads on the caller's stream
         self._stream_pool = {}

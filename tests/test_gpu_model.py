@@ -480,3 +480,24 @@ def test_one_model_two_streams_two_threads(dev):
                 assert torch.equal(got[i][k], v), (i, k)
     sids = {k[4] for k in m._plans if isinstance(k, tuple) and len(k) == 5}
     assert len(sids) >= 3                                             # default stream + the two side streams
+
+
+@pytest.mark.parametrize("radar,B,H,W", [(True, 1, 448, 800), (True, 3, 128, 160), (False, 2, 96, 128)])
+def test_two_lane_neck_equals_single_stream(dev, radar, B, H, W):
+    """model.lanes (small batches): the IDA projections issued on a side stream beside the node chain - bit for bit
+    the single-stream forward, also when repeated back to back (cross-lane events, no shared scratch)."""
+    m = _model(radar, dev, (H, W))
+    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=71, radar=radar)
+    xd, pd, cd = x.to(dev), (pc_dep.to(dev) if radar else None), calib.to(dev)
+    with torch.no_grad():
+        m.lanes = False
+        one = m(xd, pc_dep=pd, calib=cd)[0]
+        m.invalidate()
+        m.lanes = True
+        outs = [m(xd, pc_dep=pd, calib=cd)[0] for _ in range(4)]
+    plan = list(m._plans.values())[-1]
+    assert plan.use_lanes and 1 in plan.lanes
+    for y in outs:
+        for k in one:
+            if k != "calib":
+                assert torch.equal(y[k], one[k]), k
