@@ -92,7 +92,9 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     }
   }
   // the next round's patch is staged in two halves (loads of the first half fly over taps 0-3, those of
-  // the second over taps 4-8), so only half of the raw registers are live at any time
+  // the second over taps 4-8), so only half of the raw registers are live at any time.  The loads are
+  // UNCONDITIONAL - a unit outside the image reads a valid dummy address and is zeroed when it is split - so no
+  // exec-masked memory instruction sits inside the scheduling-pinned loop ("glitch")
   constexpr int NH0 = (NU + 1) / 2;
   f32x4 raw[NU];
   auto load_patch = [&](int r, int lo, int hi) {
@@ -100,8 +102,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
 #pragma unroll
     for (int it = 0; it < NU; ++it) {
       if (it < lo || it >= hi) continue;
-      raw[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (goff[it] >= 0) raw[it] = *reinterpret_cast<const f32x4*>(p.x + goff[it] + c0);
+      raw[it] = *reinterpret_cast<const f32x4*>(p.x + max(goff[it], 0) + c0);
     }
   };
   auto store_patch = [&](unsigned char* buf, int lo, int hi) {
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
       const int u = tid + NT * it;
       const int row = u / UPR, q = u % UPR;
       if (row < p.PR) {
-        const f32x4 xs = raw[it] * ASCALE;
+        const f32x4 xs = goff[it] >= 0 ? raw[it] * ASCALE : f32x4{0.f, 0.f, 0.f, 0.f};   // (a select: the dummy read may hold anything)
         uint2 hi2, lo2;
         split2(xs[0], xs[1], hi2.x, lo2.x);
         split2(xs[2], xs[3], hi2.y, lo2.y);

@@ -573,42 +573,6 @@ class _Plan:
         return [y]
 
 
-    # ------------------------------------------------------------------------------ graph replay
-    def replay(self, model, x, pc_dep, calib):
-        """The same launches as run(), captured once into a HIP graph over static input / output
-        buffers and replayed per call (hipGraphLaunch instead of ~90 kernel launches from Python).
-        Semantics are those of run(): fresh output tensors every call (copies out of the static ones),
-        `pc_hm_in` a view of the CALLER's pc_dep, `calib` the caller's tensor."""
-        if getattr(self, "graph", None) is None:
-            self.run(model, x, pc_dep, calib)                       # warm-up: one-time attribute calls, lazy init
-            torch.cuda.synchronize()
-            self.g_x = x.clone()
-            self.g_pc = pc_dep.clone() if pc_dep is not None else None
-            self.g_calib = calib.clone() if calib is not None else None
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.g_out = self.run(model, self.g_x, self.g_pc, self.g_calib)[0]
-            self.graph = g
-        self.g_x.copy_(x)
-        if self.g_pc is not None:
-            self.g_pc.copy_(pc_dep)
-        if self.g_calib is not None:
-            self.g_calib.copy_(calib)
-        self.graph.replay()
-        y, fresh = {}, {}
-        for k, v in self.g_out.items():
-            if k == "calib":
-                y[k] = calib
-            elif k == "pc_hm_in":
-                y[k] = pc_dep[:, :1]
-            else:                                                   # aliases in g_out stay aliases (depthMap / pc_hm views)
-                base = v._base if v._base is not None else v
-                if id(base) not in fresh:
-                    fresh[id(base)] = base.clone()
-                nb = fresh[id(base)]
-                y[k] = nb if v._base is None else nb.as_strided(v.size(), v.stride(), v.storage_offset() - base.storage_offset())
-        return [y]
-
 
 # ----------------------------------------------------------------------------------- the module
 class DLASeg(nn.Module):
@@ -640,6 +604,7 @@ class DLASeg(nn.Module):
             _register(self, name, tensor, is_buf)
         self._packed = None
         self._plans = {}
+        self._graphs = {}
         self._lock = threading.RLock()     # plans (buffers + argument blocks) are built / patched / launched under it
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
@@ -648,8 +613,7 @@ class DLASeg(nn.Module):
                                  # concurrent HIP streams with their own plans; heads on the caller's stream
         self._stream_pool = {}
         self.use_graph = False   # replay the forward as ONE captured HIP graph (inputs / outputs staged through
-                                 # static buffers) instead of ~90 launches from Python.  Measured: no gain - the
-                                 # path is not launch-bound (bs=1: 2.88 ms eager, 2.92 ms replay) - hence off
+                                 # static buffers) instead of ~100 launches from Python (_forward_graph)
         self.stem_fused = True   # with conv_f16: base_layer + level0 + level1 in one launch (cf_stem.hip)
         self.conv_patch = True   # 3x3 stride-1 f16x3 convs: LDS patch reuse (cf_conv3x3_f16.hip)
         self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)
@@ -661,6 +625,7 @@ class DLASeg(nn.Module):
     def invalidate(self):
         self._packed = None
         self._plans = {}
+        self._graphs = {}
 
     def _apply(self, fn, *a, **k):
         self.invalidate()
@@ -813,15 +778,58 @@ class DLASeg(nn.Module):
             if self._packed is None:
                 self._prepare(dev)
             sid = torch.cuda.current_stream(dev).cuda_stream
-            if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 4 and not self.use_graph:
-                return self._forward_concurrent(x, pc_dep, calib, B, H, W, dev, sid)
-            key = (B, H, W, dev, sid)
-            plan = self._plans.get(key)
-            if plan is None:
-                plan = self._plans[key] = _Plan(self, B, H, W, dev)
             if self.use_graph:
-                return plan.replay(self, x, pc_dep, calib)
-            return plan.run(self, x, pc_dep, calib)
+                return self._forward_graph(x, pc_dep, calib, B, H, W, dev, sid)
+            return self._forward_eager(x, pc_dep, calib, B, H, W, dev, sid)
+
+    def _forward_eager(self, x, pc_dep, calib, B, H, W, dev, sid):
+        if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 4:
+            return self._forward_concurrent(x, pc_dep, calib, B, H, W, dev, sid)
+        key = (B, H, W, dev, sid)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = _Plan(self, B, H, W, dev)
+        return plan.run(self, x, pc_dep, calib)
+
+    def _forward_graph(self, x, pc_dep, calib, B, H, W, dev, sid):
+        """model.use_graph: the whole forward - including the fork into the trunk streams and the join in front of
+        the heads - captured ONCE as a HIP graph over static input / output buffers and replayed per call (one
+        hipGraphLaunch instead of ~100-350 launches from Python: with 4 trunk streams the eager path is bound by the
+        host's launch rate).  Semantics are those of the eager forward: fresh output tensors every call (copies out
+        of the static ones), `pc_hm_in` a view of the CALLER's pc_dep, `calib` the caller's tensor."""
+        key = (B, H, W, dev, sid, "graph", self.streams)
+        g = self._graphs.get(key)
+        if g is None:
+            self._forward_eager(x, pc_dep, calib, B, H, W, dev, sid)      # warm-up: plans, one-time attribute calls
+            torch.cuda.synchronize(dev)
+            gx = x.clone()
+            gpc = pc_dep.clone() if pc_dep is not None else None
+            gcal = calib.clone() if calib is not None else None
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                cap_sid = torch.cuda.current_stream(dev).cuda_stream   # plans of the capture stream (own buffers)
+                gout = self._forward_eager(gx, gpc, gcal, B, H, W, dev, cap_sid)[0]
+            g = self._graphs[key] = (graph, gx, gpc, gcal, gout)
+        graph, gx, gpc, gcal, gout = g
+        gx.copy_(x)
+        if gpc is not None:
+            gpc.copy_(pc_dep)
+        if gcal is not None:
+            gcal.copy_(calib)
+        graph.replay()
+        y, fresh = {}, {}
+        for k, v in gout.items():
+            if k == "calib":
+                y[k] = calib
+            elif k == "pc_hm_in":
+                y[k] = pc_dep[:, :1]
+            else:                                                   # aliases in gout stay aliases (depthMap / pc_hm views)
+                base = v._base if v._base is not None else v
+                if id(base) not in fresh:
+                    fresh[id(base)] = base.clone()
+                nb = fresh[id(base)]
+                y[k] = nb if v._base is None else nb.as_strided(v.size(), v.stride(), v.storage_offset() - base.storage_offset())
+        return [y]
 
     def _forward_concurrent(self, x, pc_dep, calib, B, H, W, dev, sid):
         """Backbone + neck as `self.streams` sub-batches, each with its OWN trunk plan (own intermediate buffers)
