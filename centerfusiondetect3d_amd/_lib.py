@@ -47,7 +47,8 @@ class HeadTailArgs(C.Structure):
 class HeadFusedArgs(C.Structure):
     _fields_ = [("tail", HeadTailArgs), ("src", _f * 2), ("src_c", C.c_int32 * 2), ("n_src", C.c_int32),
                 ("slots", _f), ("K_pad", C.c_int32), ("w_first", _f * CF_MAX_HEADS),
-                ("b_first", _f * CF_MAX_HEADS), ("layout3x3", C.c_int32), ("w_out_perm", _f * CF_MAX_HEADS)]
+                ("b_first", _f * CF_MAX_HEADS), ("layout3x3", C.c_int32), ("w_out_perm", _f * CF_MAX_HEADS),
+                ("mfma16", C.c_int32)]
 
 
 class StemArgs(C.Structure):

@@ -84,6 +84,32 @@ __device__ __forceinline__ void store_hidden_tile(unsigned char* xt, const f32x1
       }
 }
 
+// the same from 16x16 accumulators (v_mfma_f32_16x16x32_bf16: lane = pixel ct*16 + (l & 15), reg r = channel
+// 64w + 16rt + 4(l >> 4) + r) of one 64-pixel half tile
+__device__ __forceinline__ void store_hidden_tile16(unsigned char* xt, const f32x4 (&acc)[4][4], const float* bias,
+                                                    int wave, int lane) {
+  const int g = lane >> 4, c16 = lane & 15;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    const int ch = wave * 64 + rt * 16 + 4 * g;
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + ch);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      float v[4], hi[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = fmaxf(acc[rt][ct][e] + bb[e], 0.0f);
+        hi[e] = bf16_rne(v[e]);
+      }
+      unsigned char* o = xt + (ct * 16 + c16) * HT_ROWB + ch * 2;
+      const u32x2 ph = {pack2(hi[0], hi[1]), pack2(hi[2], hi[3])};
+      const u32x2 pl = {pack2(v[0] - hi[0], v[1] - hi[1]), pack2(v[2] - hi[2], v[3] - hi[3])};
+      *reinterpret_cast<u32x2*>(o) = ph;
+      *reinterpret_cast<u32x2*>(o + HT_PLANE) = pl;
+    }
+  }
+}
+
 // pixel index inside a 64-pixel tile -> (image, pixel inside the image); false = outside
 struct FlatMap {       // 64 consecutive pixels of the flattened (B*H*W) index space
   int m0, M, HW;
@@ -696,6 +722,237 @@ __global__ __launch_bounds__(256, 2) void head_patch_kernel(HeadPatchK q) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The same whole-head patch kernel on v_mfma_f32_16x16x32_bf16.  Under the chip's power management a dense MFMA
+// loop on random data holds a higher clock with the 16x16x32 shape than with 32x32x16 at equal cycles per FLOP:
+// measured on this part 1.72 vs 1.51 PFLOP/s with every operand re-read from LDS (tools/micro/mfma_shape.hip,
+// MI355X_MICROARCH.md "DVFS give-back" item 7) - and this kernel is bound by exactly that loop.  Same tile (8 x 16
+// pixels), same LDS patch, same operand bytes per FLOP: a wave owns 64 hidden channels x 128 pixels as 4 x 8
+// accumulators of 16 x 16; a k-step is 32 deep = half the channels of one tap (or four taps of the 8-channel pc_hm
+// plane pair).  Weights come as [16-row tile][k32 step][hi|lo][lane][8] fragments (packing.pack_fragments16), one
+// k-step ahead in registers.  The 256 -> n_out layer again runs from the accumulator registers: two stacked 16 x 16
+// tiles give a lane 4 + 4 channels of one pixel = one B fragment, with w_out packed in that k order
+// (pack_fragments16(acc_order=True)); n_out <= 16.
+// ---------------------------------------------------------------------------------------------
+template <int NS, bool PC>
+__global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
+  static_assert(NS == 4, "64 feature channels");
+  constexpr int ROWB = NS * 64 + (PC ? 32 : 0) + 16;     // odd multiple of 16 B
+  constexpr int NKF = 9 * NS / 2;                        // k32-steps of the feature channels
+  constexpr int NK = NKF + (PC ? 3 : 0);
+  extern __shared__ __attribute__((aligned(16))) unsigned char xt[];
+  const HeadTailK& p = q.t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  const int per_img = q.tiles_x * q.tiles_y;
+  const int per_head = per_img * (p.M / p.HW);
+  int head, rem;
+  if (q.group == 0) {
+    head = blockIdx.x / per_head;
+    rem = blockIdx.x - head * per_head;
+  } else {
+    const int gg = q.group;
+    const int per_group = per_head * gg;
+    const int grp = blockIdx.x / per_group;
+    const int lb = cf_xcd_remap(blockIdx.x - grp * per_group, per_group);
+    rem = lb / gg;
+    head = grp * gg + (lb - rem * gg);
+    if (head >= p.n_heads) return;
+  }
+  const int b = rem / per_img;
+  rem -= b * per_img;
+  const int y0 = (rem / q.tiles_x) * HP_TH, x0 = (rem % q.tiles_x) * HP_TW;
+  const unsigned char* w1 = q.w_first[head];
+
+  // ---- patch -> LDS (one pass, every load in flight before the first LDS write)
+  {
+    constexpr int UPR = NS * 4;                            // 16-byte units per row: hi plane then lo plane
+    constexpr int NIT = (HP_ROWS * UPR + 255) / 256;
+    u32x4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx / UPR, u = idx % UPR;
+      const int y = y0 - 1 + row / HP_PW, x = x0 - 1 + row % HP_PW;
+      v[it] = u32x4{0u, 0u, 0u, 0u};
+      if (row < HP_ROWS && (unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W)
+        v[it] = *reinterpret_cast<const u32x4*>(q.src[0] + ((size_t)(b * p.HW + y * q.W + x) * 2 * q.src_c[0]) * 2 +
+                                                (u / (NS * 2)) * q.src_c[0] * 2 + (u % (NS * 2)) * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx / UPR, u = idx % UPR;
+      const int plane = u / (NS * 2), uu = u % (NS * 2);
+      if (row < HP_ROWS) *reinterpret_cast<u32x4*>(xt + row * ROWB + (uu >> 1) * 64 + plane * 32 + (uu & 1) * 16) = v[it];
+    }
+    if (PC) {
+      for (int idx = tid; idx < HP_ROWS * 2; idx += 256) {
+        const int row = idx >> 1, plane = idx & 1;
+        const int y = y0 - 1 + row / HP_PW, x = x0 - 1 + row % HP_PW;
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if ((unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W)
+          w = *reinterpret_cast<const u32x4*>(q.src[1] + ((size_t)(b * p.HW + y * q.W + x) * 2 + plane) * q.src_c[1] * 2);
+        *reinterpret_cast<u32x4*>(xt + row * ROWB + NS * 64 + plane * 16) = w;
+      }
+    }
+  }
+
+  // B fragment of a 16x16x32 MFMA: lane (g = l >> 4, c = l & 15) holds 8 consecutive channels 8g .. 8g+7 of the
+  // k-step's 32 for pixel column c of the 16-pixel tile row
+  int rowb[8];                               // LDS byte offset of this lane's pixel in tile row ct (tap (-1,-1))
+#pragma unroll
+  for (int ct = 0; ct < 8; ++ct) rowb[ct] = (ct * HP_PW + c16) * ROWB;
+  const int koff = (g >> 1) * 64 + (g & 1) * 16;         // 8-channel group inside a 32-channel half (hi plane; lo at +32)
+  int pc_off[3];                             // pc_hm steps: k-group g of step i is tap 4i + g (taps 9..11: zero weights)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int t = min(4 * i + g, 8);
+    pc_off[i] = ((t / 3) * HP_PW + t % 3) * ROWB + NS * 64;
+  }
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[a][c][r] = 0.0f;
+
+  bf16x8 wh[2][4], wl[2][4];                 // weight fragments one k-step ahead: set ks & 1
+  auto load_w = [&](bf16x8 (&dh)[4], bf16x8 (&dl)[4], int ks) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      dh[rt] = *wfrag(w1, wave * 4 + rt, ks, 0, q.n_ks, lane);
+      dl[rt] = *wfrag(w1, wave * 4 + rt, ks, 1, q.n_ks, lane);
+    }
+  };
+  load_w(wh[0], wl[0], 0);
+  __syncthreads();
+
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    if (ks + 1 < NK) load_w(wh[(ks + 1) & 1], wl[(ks + 1) & 1], ks + 1);
+    int off, lo;
+    if (ks < NKF) {
+      const int tap = ks / (NS / 2), half = ks % (NS / 2);
+      off = ((tap / 3) * HP_PW + tap % 3) * ROWB + half * 128 + koff;
+      lo = 32;
+    } else {
+      off = pc_off[ks - NKF < 3 ? ks - NKF : 0];
+      lo = 16;
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {         // tile rows 0-3, then 4-7: half of the B fragments live at a time
+      bf16x8 xh[4], xl[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        xh[ct] = *reinterpret_cast<const bf16x8*>(xt + rowb[4 * hf + ct] + off);
+        xl[ct] = *reinterpret_cast<const bf16x8*>(xt + rowb[4 * hf + ct] + off + lo);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[rt][4 * hf + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks & 1][rt], xh[ct], acc[rt][4 * hf + ct], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[rt][4 * hf + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks & 1][rt], xl[ct], acc[rt][4 * hf + ct], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[rt][4 * hf + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks & 1][rt], xh[ct], acc[rt][4 * hf + ct], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  if (p.n_hidden > 0) {
+    // hidden layers need all 256 channels of a pixel: the two 64-pixel halves of the tile go through
+    // the LDS-resident chain of cf_head_tail one after the other (LDS stays at 66 KiB: 2 workgroups/CU)
+    __syncthreads();                         // every wave is done with the patch
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4 a2[4][4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) a2[rt][ct] = acc[rt][4 * half + ct];
+      store_hidden_tile16(xt, a2, q.b_first[head], wave, lane);
+      __syncthreads();
+      head_tail_from_lds(p, xt, head, TileMap{b, y0 + 4 * half, x0, q.H, q.W});
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- output layer from registers: this wave's 64 hidden channels = 2 k-steps of 32
+  f32x4 oacc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) oacc[c][r] = 0.0f;
+  {
+    const float* b1 = q.b_first[head] + wave * 64 + 4 * g;
+    const unsigned char* wo = q.w_out_perm[head];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int ks2 = wave * 2 + s2;
+      const bf16x8 ah = *wfrag(wo, 0, ks2, 0, 8, lane), al = *wfrag(wo, 0, ks2, 1, 8, lane);
+      const f32x4 ba = *reinterpret_cast<const f32x4*>(b1 + 32 * s2);
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b1 + 32 * s2 + 16);
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        float v[8], hi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[j] = fmaxf(acc[2 * s2 + (j >> 2)][ct][j & 3] + (j < 4 ? ba[j] : bb[j - 4]), 0.0f);
+          hi[j] = bf16_rne(v[j]);
+        }
+        const u32x4 ph = {pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7])};
+        const u32x4 pl = {pack2(v[0] - hi[0], v[1] - hi[1]), pack2(v[2] - hi[2], v[3] - hi[3]),
+                          pack2(v[4] - hi[4], v[5] - hi[5]), pack2(v[6] - hi[6], v[7] - hi[7])};
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, ph), xl = __builtin_bit_cast(bf16x8, pl);
+        oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, oacc[ct], 0, 0, 0);
+        oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, oacc[ct], 0, 0, 0);
+        oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, oacc[ct], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                           // every wave is done with the patch: reuse LDS for the partial sums
+  const int n_out = p.n_out[head], act = p.act[head];
+  float* red = reinterpret_cast<float*>(xt); // [wave][n 16][px 128]
+#pragma unroll
+  for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 4 * g + r;
+      if (n < n_out) red[(wave * 16 + n) * HP_PX + ct * 16 + c16] = oacc[ct][r];
+    }
+  __syncthreads();
+  {
+    const int px = tid & (HP_PX - 1);
+    const int y = y0 + (px >> 4), x = x0 + (px & 15);
+    if (y < q.H && x < q.W) {
+      const float* bo = p.b_out[head];
+      float* out = p.out[head];
+      float* out2 = p.out2[head];
+      for (int n = tid >> 7; n < n_out; n += 2) {
+        const float raw = red[n * HP_PX + px] + red[(16 + n) * HP_PX + px] + red[(32 + n) * HP_PX + px] +
+                          red[(48 + n) * HP_PX + px] + bo[n];
+        const size_t o = ((size_t)b * n_out + n) * p.HW + (size_t)y * q.W + x;
+        float v = raw;
+        if (act == CF_ACT_RELU) v = fmaxf(raw, 0.0f);
+        else if (act == CF_ACT_SIGMOID_CLAMP) v = fminf(fmaxf(cf_sigmoid(raw), 1e-4f), 1.0f - 1e-4f);
+        out[o] = v;
+        if (act == CF_ACT_RAW_AND_SIGDEPTH) out2[o] = 1.0f / (cf_sigmoid(raw) + 1e-6f) - 1.0f;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int fill_tail(const cf_head_tail_args* a, HeadTailK& k, const char* who, bool need_x) {
@@ -776,8 +1033,14 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
     hp.H = k.H; hp.W = k.W;
     hp.tiles_x = (k.W + HP_TW - 1) / HP_TW;
     hp.tiles_y = (k.H + HP_TH - 1) / HP_TH;
-    hp.n_ks = a->K_pad / 16;
-    CF_REQUIRE(hp.n_ks >= (a->n_src == 2 ? 41 : 36), "cf_head_fused: K_pad=%d too small for the 3x3 layout", a->K_pad);
+    const bool m16 = a->mfma16 != 0;         // fragments packed for v_mfma_f32_16x16x32_bf16 (k-steps of 32)
+    hp.n_ks = m16 ? a->K_pad / 32 : a->K_pad / 16;
+    CF_REQUIRE(a->K_pad / 16 >= (a->n_src == 2 ? 41 : 36), "cf_head_fused: K_pad=%d too small for the 3x3 layout", a->K_pad);
+    if (m16) {
+      CF_REQUIRE(a->K_pad % 32 == 0 && a->K_pad / 32 >= (a->n_src == 2 ? 21 : 18), "cf_head_fused: K_pad=%d (16x16x32 fragments)", a->K_pad);
+      for (int i = 0; i < a->tail.n_heads; ++i)
+        CF_REQUIRE(a->tail.n_hidden > 0 || a->tail.n_out[i] <= 16, "cf_head_fused: head %d: n_out=%d > 16 (16x16x32 output tile)", i, a->tail.n_out[i]);
+    }
     for (int i = 0; i < a->tail.n_heads; ++i) {
       CF_REQUIRE(a->tail.n_hidden > 0 || a->w_out_perm[i], "cf_head_fused: head %d: w_out_perm missing", i);
       hp.w_first[i] = k.w_first[i];
@@ -798,6 +1061,16 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
     static CfLdsLimit lim_plain, lim_pc;
     lim_plain.ensure(head_patch_kernel<4, false>, HP_LDS, HP_LDS);
     lim_pc.ensure(head_patch_kernel<4, true>, HP_LDS, HP_LDS);
+    if (m16) {
+      static CfLdsLimit lim16_plain, lim16_pc;
+      lim16_plain.ensure(head_patch16_kernel<4, false>, HP_LDS, HP_LDS);
+      lim16_pc.ensure(head_patch16_kernel<4, true>, HP_LDS, HP_LDS);
+      if (a->n_src == 2)
+        hipLaunchKernelGGL((head_patch16_kernel<4, true>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
+      else
+        hipLaunchKernelGGL((head_patch16_kernel<4, false>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
+      return cf_check_launch("cf_head_fused");
+    }
     if (a->n_src == 2)
       hipLaunchKernelGGL((head_patch_kernel<4, true>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
     else

@@ -618,6 +618,8 @@ class DLASeg(nn.Module):
         self.conv_patch = True   # 3x3 stride-1 f16x3 convs: LDS patch reuse (cf_conv3x3_f16.hip)
         self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)
         self.heads_fused = True  # with heads_bf16: one launch per head group, hidden maps stay in LDS
+        self.heads_mfma16 = True # fused heads: first layer + register-fed output layer on v_mfma_f32_16x16x32_bf16 (the
+                                 # shape that holds the higher clock under load: 1.72 vs 1.51 PFLOP/s measured)
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
         self.eval()
 
@@ -732,17 +734,19 @@ class DLASeg(nn.Module):
                     pk[f"heads.{h}.{idx}"] = pack(hw(h, idx), hb(h, idx), [Source(256, ns, 256 * n)]).to(device)
                 pk[f"heads.{h}.out"] = pack(hw(h, 6), hb(h, 6), [Source(256, ns, 256 * n)]).to(device)
         if bf:
+            m16 = bool(self.heads_mfma16) and all(n <= 16 for n in heads.values())
             def tail(h, hidden_idx, out_idx):
                 n_out = heads[h]
                 b32 = torch.zeros(32)
                 b32[:n_out] = hb(h, out_idx)
+                w2 = hw(h, out_idx).view(n_out, 256)
+                perm = (packing.pack_fragments16(w2, acc_order=True) if m16 else packing.pack_fragments(w2, acc_order=True))
                 return dict(w_hidden=[packing.pack_fragments(hw(h, i).view(256, 256)).to(device) for i in hidden_idx],
                             b_hidden=[hb(h, i).to(device) for i in hidden_idx],
-                            w_out=packing.pack_fragments(hw(h, out_idx).view(n_out, 256)).to(device),
-                            w_out_perm=packing.pack_fragments(hw(h, out_idx).view(n_out, 256), acc_order=True).to(device),
-                            b_out=b32.to(device), n_out=n_out)
+                            w_out=packing.pack_fragments(w2).to(device), w_out_perm=perm.to(device),
+                            b_out=b32.to(device), n_out=n_out, mfma16=m16)
             def first(h, srcs):
-                pc = packing.pack_conv_bf16(hw(h, 0), hb(h, 0), srcs, fragments=True).to(device)
+                pc = packing.pack_conv_bf16(hw(h, 0), hb(h, 0), srcs, fragments=16 if m16 else True).to(device)
                 return dict(w_first=pc.weight, b_first=pc.bias[:256].contiguous(), slots=pc.slots, k_pad=pc.k_pad,
                             real_cin=pc.real_cin)
             pk["tails.primary"] = {h: dict(tail(h, [], 2), **first(h, [feat_src])) for h in primary}

@@ -160,6 +160,7 @@ def head_fused_args(srcs, src_strides, slots, k_pad, B, H, W, heads, layout3x3=N
         if hd.get("w_out_perm") is not None:
             f.w_out_perm[i] = hd["w_out_perm"].data_ptr()
     f.layout3x3 = int(all(hd.get("w_out_perm") is not None for hd in heads)) if layout3x3 is None else int(layout3x3)
+    f.mfma16 = int(all(bool(hd.get("mfma16")) for hd in heads))     # fragments packed for the 16x16x32 shape
     return f
 
 

@@ -132,7 +132,9 @@ def pack_conv_bf16(weight, bias, sources: Sequence[Source], stride=1, pad=None, 
             w[:co, 8 * j:8 * j + real] = wf[:, c0:c0 + real, r, q]
     b = torch.zeros(n_pad)
     b[:co] = bias
-    if fragments:          # cf_head_fused: A-operand fragment order instead of [N][2][K]
+    if fragments == 16:    # cf_head_fused with mfma16: 16x16x32 fragments
+        wt = pack_fragments16(w)
+    elif fragments:        # cf_head_fused: A-operand fragment order instead of [N][2][K]
         wt = pack_fragments(w)
     else:
         hi = w.to(torch.bfloat16)
@@ -225,6 +227,31 @@ def pack_fragments(weight2d, n_pad=None, acc_order=False):
     f = planes.view(2, n_pad // 32, 32, k // 16, 2, 8)                  # p, rt, i, ks, h, j
     f = f.permute(1, 3, 0, 4, 2, 5).contiguous()                        # rt, ks, p, h, i, j
     return f.view(n_pad // 32, k // 16, 2, 64, 8)
+
+
+def pack_fragments16(weight2d, n_pad=None, acc_order=False):
+    """(N, K) fp32 -> A-operand fragment order of v_mfma_f32_16x16x32_bf16 (cf_head_fused with mfma16):
+    uint8 view of [N_pad/16][K/32][2 (hi, lo)][64 lanes][8 bf16]; lane (i = l & 15, g = l >> 4) holds
+    W[16 rt + i][32 ks + 8 g + j], j = 0..7.
+    acc_order (K = 256, the head output layer fed from accumulator registers): position (ks, g, j) holds hidden
+    channel 64 (ks >> 1) + 16 (2 (ks & 1) + (j >> 2)) + 4 g + (j & 3) - the channels a lane of wave ks >> 1 finds
+    in the two stacked 16 x 16 accumulators 2 (ks & 1), 2 (ks & 1) + 1."""
+    n, k = weight2d.shape
+    assert k % 32 == 0
+    n_pad = n_pad or ((n + 15) // 16) * 16
+    w = torch.zeros(n_pad, k)
+    w[:n] = weight2d.float()
+    if acc_order:
+        assert k % 64 == 0
+        perm = torch.tensor([64 * (ks >> 1) + 16 * (2 * (ks & 1) + (j >> 2)) + 4 * g + (j & 3)
+                             for ks in range(k // 32) for g in range(4) for j in range(8)])
+        w = w[:, perm]
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    planes = torch.stack([hi, lo], 0)                                   # (2, N, K)
+    f = planes.view(2, n_pad // 16, 16, k // 32, 4, 8)                  # p, rt, i, ks, g, j
+    f = f.permute(1, 3, 0, 4, 2, 5).contiguous()                        # rt, ks, p, g, i, j
+    return f.view(n_pad // 16, k // 32, 2, 64, 8)
 
 
 @dataclass

@@ -175,6 +175,12 @@ typedef struct cf_head_fused_args {
                                               may run on the 2-D patch kernel (no slot table reads)                 */
   const void* w_out_perm[CF_MAX_HEADS];    /* layout3x3 && n_hidden == 0: w_out with the k order of an accumulator
                                               register group (position 8h+j of a 16-group = channel 4h+(j&3)+8(j>>2)) */
+  int32_t mfma16;                          /* layout3x3 only.  != 0: w_first[] and w_out_perm[] are packed for
+                                              v_mfma_f32_16x16x32_bf16 - [16-row tile][k step of 32][hi,lo][lane 64][8 bf16],
+                                              lane l = row l & 15, k 8 (l >> 4) + j (packing.pack_fragments16); w_out_perm is
+                                              ONE 16-row tile whose k position (step ks, group g, j) holds hidden channel
+                                              64 (ks >> 1) + 16 (2 (ks & 1) + (j >> 2)) + 4 g + (j & 3); n_out <= 16.  The launch
+                                              then runs on the 16x16x32 patch kernel (1.14x the 32x32x16 rate under load) */
 } cf_head_fused_args;
 int cf_head_fused(const cf_head_fused_args* a, void* stream);
 

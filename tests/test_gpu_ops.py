@@ -417,10 +417,18 @@ def test_head_tail_fused_chain(dev, n_hidden, B, H, W):
     (0, False, 3, 16, 32, True),      # ... exact tiling
     (2, True, 2, 13, 19, True),       # hidden layers behind the patch first layer (two 64-pixel halves)
     (1, False, 1, 8, 40, True),
+    (0, False, 2, 9, 14, 16),         # the same on the 16x16x32 MFMA shape (fragments packed by pack_fragments16)
+    (0, True, 1, 21, 37, 16),
+    (0, False, 3, 16, 32, 16),
+    (2, True, 2, 13, 19, 16),
+    (1, False, 1, 8, 40, 16),
 ])
 def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W, patch):
     """3x3 conv (feat [|| pc_hm]) + ReLU -> hidden chain -> output, one launch, vs fp32 torch.
-    patch: heads without hidden layers on the 2-D LDS-patch kernel (w_out_perm given)."""
+    patch: heads without hidden layers on the 2-D LDS-patch kernel (w_out_perm given); patch == 16: that kernel's
+    v_mfma_f32_16x16x32_bf16 form."""
+    m16 = patch == 16
+    patch = bool(patch)
     from centerfusiondetect3d_amd import ops, packing
     n_outs, acts = [10, 1, 3, 8], [2, 3, 0, 0]
     feat, pch = rnd(B, 64, H, W, seed=1), rnd(B, 3, H, W, seed=2)
@@ -432,7 +440,7 @@ def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W, patch):
     for i, (no, act) in enumerate(zip(n_outs, acts)):
         w1, b1 = rnd(256, ci, 3, 3, seed=300 + i, scale=(ci * 9) ** -0.5), rnd(256, seed=310 + i, scale=0.1)
         x = F.relu(F.conv2d(xin, w1, b1, 1, 1))
-        pc = packing.pack_conv_bf16(w1, b1, sources, fragments=True).to(dev)
+        pc = packing.pack_conv_bf16(w1, b1, sources, fragments=16 if m16 else True).to(dev)
         slots, k_pad = pc.slots, pc.k_pad
         wh, bh = [], []
         for l in range(n_hidden):
@@ -446,11 +454,12 @@ def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W, patch):
         out2 = torch.full((B, no, H, W), float("nan"), device=dev) if act == 3 else None
         heads.append(dict(w_first=pc.weight, b_first=pc.bias[:256].contiguous(), w_hidden=wh, b_hidden=bh,
                           w_out=packing.pack_fragments(w.view(no, 256)).to(dev), b_out=b32.to(dev),
-                          w_out_perm=packing.pack_fragments(w.view(no, 256), acc_order=True).to(dev) if patch else None,
-                          n_out=no, act=act, out=out, out2=out2))
+                          w_out_perm=((packing.pack_fragments16 if m16 else packing.pack_fragments)(
+                              w.view(no, 256), acc_order=True).to(dev) if patch else None),
+                          mfma16=m16, n_out=no, act=act, out=out, out2=out2))
         refs.append(raw)
     f = ops.head_fused_args(srcs, [s.shape[-1] for s in srcs], slots, k_pad, B, H, W, heads)
-    assert f.layout3x3 == int(patch)
+    assert f.layout3x3 == int(patch) and f.mfma16 == int(m16)
     ops.run_head_fused(f)
     for hd, raw in zip(heads, refs):
         scale = float(raw.abs().max())
