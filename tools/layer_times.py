@@ -12,6 +12,7 @@ ap.add_argument("--fp32-heads", action="store_true")
 ap.add_argument("--no-precise", action="store_true")
 ap.add_argument("--fp32-convs", action="store_true")
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--heads-mfma32", action="store_true", help="head kernels on the 32x32x16 MFMA shape (A/B)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 H, W = 448, 800
@@ -19,6 +20,7 @@ m = getModel(centerfusion_middle_config((H, W)))
 m.heads_bf16 = not a.fp32_heads
 m.precise = not a.no_precise
 m.conv_f16 = not a.fp32_convs
+m.heads_mfma16 = not a.heads_mfma32
 m.streams = 1          # per-launch event timing needs one stream
 m = bench.synthetic_weights(m).to(dev).eval()
 images, pc_dep, calib = bench.make_inputs(a.batch, H, W, dev, 1000)
