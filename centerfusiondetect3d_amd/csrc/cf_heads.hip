@@ -251,6 +251,119 @@ __device__ __forceinline__ void head_tail_from_lds(const HeadTailK& p, unsigned 
   reduce_and_store(p, xt, oacc, head, pm);
 }
 
+// The same chain on v_mfma_f32_16x16x32_bf16 (weights packed by pack_fragments16: w_hidden [16 rt][8 ks], w_out one
+// 16-row tile): wave w owns channels [64w, 64w+64) x 64 pixels as 4 x 4 accumulators of 16 x 16; a k-step is 32 deep.
+template <class PixMap>
+__device__ __forceinline__ void head_tail_from_lds16(const HeadTailK& p, unsigned char* xt, int head, const PixMap& pm) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c16 = lane & 15;
+  for (int l = 0; l < p.n_hidden; ++l) {
+    const unsigned char* w = p.w_hidden[head][l];
+    const float* bias = p.b_hidden[head][l];
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.0f;
+    bf16x8 wh[2][4], wl[2][4];               // one k-step ahead: set ks & 1
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      wh[0][rt] = *wfrag(w, wave * 4 + rt, 0, 0, 8, lane);
+      wl[0][rt] = *wfrag(w, wave * 4 + rt, 0, 1, 8, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks + 1 < 8) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          wh[(ks + 1) & 1][rt] = *wfrag(w, wave * 4 + rt, ks + 1, 0, 8, lane);
+          wl[(ks + 1) & 1][rt] = *wfrag(w, wave * 4 + rt, ks + 1, 1, 8, lane);
+        }
+      }
+      bf16x8 xh[4], xl[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const unsigned char* row = xt + (ct * 16 + c16) * HT_ROWB + (ks * 32 + g * 8) * 2;
+        xh[ct] = *reinterpret_cast<const bf16x8*>(row);
+        xl[ct] = *reinterpret_cast<const bf16x8*>(row + HT_PLANE);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks & 1][rt], xh[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks & 1][rt], xl[ct], acc[rt][ct], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks & 1][rt], xh[ct], acc[rt][ct], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // every wave has read the whole tile: rewrite it in place
+    store_hidden_tile16(xt, acc, bias, wave, lane);
+    __syncthreads();
+  }
+
+  // ---- output layer: wave w takes k in [64w, 64w+64) = 2 k-steps
+  f32x4 oacc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) oacc[b][r] = 0.0f;
+  {
+    const unsigned char* w = p.w_out[head];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int ks = wave * 2 + s2;
+      const bf16x8 ah = *wfrag(w, 0, ks, 0, 8, lane), al = *wfrag(w, 0, ks, 1, 8, lane);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const unsigned char* row = xt + (ct * 16 + c16) * HT_ROWB + (ks * 32 + g * 8) * 2;
+        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(row);
+        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(row + HT_PLANE);
+        oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, oacc[ct], 0, 0, 0);
+        oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, oacc[ct], 0, 0, 0);
+        oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, oacc[ct], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();  // tile no longer needed: reuse LDS for the 4 partial sums [wave][n 16][px 64]
+  float* red = reinterpret_cast<float*>(xt);
+  const int n_out = p.n_out[head], act = p.act[head];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 4 * g + r;
+      if (n < n_out) red[(wave * 16 + n) * HT_PX + ct * 16 + c16] = oacc[ct][r];
+    }
+  __syncthreads();
+  const float* bo = p.b_out[head];
+  float* out = p.out[head];
+  float* out2 = p.out2[head];
+  const int px = tid & 63;
+  int b, pix;
+  if (pm(px, b, pix)) {
+    for (int n = tid >> 6; n < n_out; n += 4) {
+      const float raw = red[n * HT_PX + px] + red[(16 + n) * HT_PX + px] + red[(32 + n) * HT_PX + px] +
+                        red[(48 + n) * HT_PX + px] + bo[n];
+      const size_t o = ((size_t)b * n_out + n) * p.HW + pix;
+      float v = raw;
+      if (act == CF_ACT_RELU) v = fmaxf(raw, 0.0f);
+      else if (act == CF_ACT_SIGMOID_CLAMP) v = fminf(fmaxf(cf_sigmoid(raw), 1e-4f), 1.0f - 1e-4f);
+      out[o] = v;
+      if (act == CF_ACT_RAW_AND_SIGDEPTH) out2[o] = 1.0f / (cf_sigmoid(raw) + 1e-6f) - 1.0f;
+    }
+  }
+}
+
 // Tail only: the 256-channel hidden tile comes from a split-bf16 tensor in HBM.
 __global__ __launch_bounds__(256) void head_tail_kernel(HeadTailK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xt[];  // [2 planes][64 px][528 B]
@@ -882,7 +995,7 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
         for (int ct = 0; ct < 4; ++ct) a2[rt][ct] = acc[rt][4 * half + ct];
       store_hidden_tile16(xt, a2, q.b_first[head], wave, lane);
       __syncthreads();
-      head_tail_from_lds(p, xt, head, TileMap{b, y0 + 4 * half, x0, q.H, q.W});
+      head_tail_from_lds16(p, xt, head, TileMap{b, y0 + 4 * half, x0, q.H, q.W});
       __syncthreads();
     }
     return;

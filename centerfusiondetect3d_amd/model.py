@@ -741,9 +741,10 @@ class DLASeg(nn.Module):
                 b32[:n_out] = hb(h, out_idx)
                 w2 = hw(h, out_idx).view(n_out, 256)
                 perm = (packing.pack_fragments16(w2, acc_order=True) if m16 else packing.pack_fragments(w2, acc_order=True))
-                return dict(w_hidden=[packing.pack_fragments(hw(h, i).view(256, 256)).to(device) for i in hidden_idx],
+                pf = packing.pack_fragments16 if m16 else packing.pack_fragments
+                return dict(w_hidden=[pf(hw(h, i).view(256, 256)).to(device) for i in hidden_idx],
                             b_hidden=[hb(h, i).to(device) for i in hidden_idx],
-                            w_out=packing.pack_fragments(w2).to(device), w_out_perm=perm.to(device),
+                            w_out=pf(w2).to(device), w_out_perm=perm.to(device),
                             b_out=b32.to(device), n_out=n_out, mfma16=m16)
             def first(h, srcs):
                 pc = packing.pack_conv_bf16(hw(h, 0), hb(h, 0), srcs, fragments=16 if m16 else True).to(device)

@@ -179,7 +179,8 @@ typedef struct cf_head_fused_args {
                                               v_mfma_f32_16x16x32_bf16 - [16-row tile][k step of 32][hi,lo][lane 64][8 bf16],
                                               lane l = row l & 15, k 8 (l >> 4) + j (packing.pack_fragments16); w_out_perm is
                                               ONE 16-row tile whose k position (step ks, group g, j) holds hidden channel
-                                              64 (ks >> 1) + 16 (2 (ks & 1) + (j >> 2)) + 4 g + (j & 3); n_out <= 16.  The launch
+                                              64 (ks >> 1) + 16 (2 (ks & 1) + (j >> 2)) + 4 g + (j & 3); n_out <= 16; tail.w_hidden[][] ([16 tiles][8 k steps])
+                                              and tail.w_out[] (one 16-row tile, natural k order) are 16x16x32 fragments too.  The launch
                                               then runs on the 16x16x32 patch kernel (1.14x the 32x32x16 rate under load) */
 } cf_head_fused_args;
 int cf_head_fused(const cf_head_fused_args* a, void* stream);

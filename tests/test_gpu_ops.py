@@ -446,14 +446,14 @@ def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W, patch):
         for l in range(n_hidden):
             w, b = rnd(256, 256, 1, 1, seed=10 * i + l, scale=1 / 16), rnd(256, seed=50 + 10 * i + l, scale=0.1)
             x = F.relu(F.conv2d(x, w, b))
-            wh.append(packing.pack_fragments(w.view(256, 256)).to(dev)); bh.append(b.to(dev))
+            wh.append((packing.pack_fragments16 if m16 else packing.pack_fragments)(w.view(256, 256)).to(dev)); bh.append(b.to(dev))
         w, b = rnd(no, 256, 1, 1, seed=100 + i, scale=1 / 16), rnd(no, seed=200 + i)
         raw = F.conv2d(x, w, b)
         b32 = torch.zeros(32); b32[:no] = b
         out = torch.full((B, no, H, W), float("nan"), device=dev)
         out2 = torch.full((B, no, H, W), float("nan"), device=dev) if act == 3 else None
         heads.append(dict(w_first=pc.weight, b_first=pc.bias[:256].contiguous(), w_hidden=wh, b_hidden=bh,
-                          w_out=packing.pack_fragments(w.view(no, 256)).to(dev), b_out=b32.to(dev),
+                          w_out=(packing.pack_fragments16 if m16 else packing.pack_fragments)(w.view(no, 256)).to(dev), b_out=b32.to(dev),
                           w_out_perm=((packing.pack_fragments16 if m16 else packing.pack_fragments)(
                               w.view(no, 256), acc_order=True).to(dev) if patch else None),
                           mfma16=m16, n_out=no, act=act, out=out, out2=out2))
