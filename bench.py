@@ -38,10 +38,10 @@ DOMINANT = ["tails.primary", "tails.secondary"]
 # HBM-side bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes over this same command (FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md §HBM); bench.py cannot
 # run the profiler on itself, so the committed measurement is reported.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_e_pmc_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
 
 
-def measured_traffic(kernels=("head_patch_kernel<4, false>", "head_patch_kernel<4, true>")):
+def measured_traffic(kernels=("head_patch16_kernel<4, false>", "head_patch16_kernel<4, true>")):
     """Average HBM-side bytes per launch over the dominant kernel's two instantiations."""
     try:
         t = json.load(open(TRAFFIC_FILE))
@@ -346,7 +346,7 @@ def main():
                          "traffic": None if args.exact_fp32 else measured_traffic(),
                          "kernel": ("conv_igemm_kernel (fp32 MFMA; the 3x3 first layers of the 7 primary / 4 secondary heads)"
                                     if args.exact_fp32 else
-                                    "head_patch_kernel (cf_head_fused; 2 launches/step: 7 primary heads, 4 secondary heads)"),
+                                    "head_patch16_kernel (cf_head_fused, v_mfma_f32_16x16x32_bf16; 2 launches/step: 7 primary heads, 4 secondary heads)"),
                          "note": ("algorithmic FLOPs (2*MACs) against the fp32 MFMA peak" if args.exact_fp32 else
                                   "algorithmic FLOPs (2*MACs); the kernel issues 3 bf16 MFMA passes per MAC "
                                   "(split operands), so MFMA-pipe utilisation is 3x frac"),

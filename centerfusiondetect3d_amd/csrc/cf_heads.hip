@@ -601,13 +601,20 @@ constexpr int HP_TH = 8, HP_TW = 16, HP_PW = HP_TW + 2, HP_ROWS = (HP_TH + 2) * 
 constexpr int HP_PX = HP_TH * HP_TW;                                                    // 128
 constexpr int HP_RED = 4 * 32 * HP_PX * 4;                                              // 64 KiB of partial sums
 constexpr int HP_LDS = HT_LDS > HP_RED ? HT_LDS : HP_RED;   // patch (<= 55 KiB) / partial sums / 64-pixel hidden tile
+constexpr int HP16_RED = 4 * 16 * HP_PX * 4;   // 16x16x32 kernel: partial sums [wave][16][128] BEHIND the patch
+constexpr int hp16_patch_bytes(bool pc) { return HP_ROWS * (4 * 64 + (pc ? 32 : 0) + 16); }   // 48,960 / 54,720
+// without pc_hm: 48,960 + 32,768 = 81,728 B <= half of the CU's 160 KiB: still two workgroups per CU
+constexpr int hp16_lds(bool pc, bool hidden) {
+  return hidden ? (HT_LDS > hp16_patch_bytes(pc) ? HT_LDS : hp16_patch_bytes(pc)) : hp16_patch_bytes(pc) + HP16_RED;
+}
 
 struct HeadPatchK {
   HeadTailK t;
   const unsigned char* src[2];
   int src_c[2];
   int H, W, tiles_x, tiles_y, n_ks;
-  int group;                                 // 0: head-major grid; g > 0: tile-major within groups of g heads
+  int group;                                 // 0: head-major grid; g > 0: tile-major within groups of g heads (32x32x16 kernel)
+  int hloop;                                 // 16x16x32 kernel: consecutive heads one workgroup walks on its patch
   const unsigned char* w_first[CF_MAX_HEADS];
   const float* b_first[CF_MAX_HEADS];
   const unsigned char* w_out_perm[CF_MAX_HEADS];
@@ -860,23 +867,16 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   const int g = lane >> 4, c16 = lane & 15;
   const int per_img = q.tiles_x * q.tiles_y;
   const int per_head = per_img * (p.M / p.HW);
-  int head, rem;
-  if (q.group == 0) {
-    head = blockIdx.x / per_head;
-    rem = blockIdx.x - head * per_head;
-  } else {
-    const int gg = q.group;
-    const int per_group = per_head * gg;
-    const int grp = blockIdx.x / per_group;
-    const int lb = cf_xcd_remap(blockIdx.x - grp * per_group, per_group);
-    rem = lb / gg;
-    head = grp * gg + (lb - rem * gg);
-    if (head >= p.n_heads) return;
-  }
+  // grid = (head range, tile): a workgroup keeps its patch in LDS and walks q.hloop consecutive heads on it (heads
+  // without hidden layers only: the hidden chain rewrites the patch area).  Head-range-major order, so the
+  // workgroups in flight work on the same few heads and their first-layer weights stay hot in L2, while the patch
+  // is read from HBM once per range instead of once per head.
+  const int hg = blockIdx.x / per_head;
+  int rem = blockIdx.x - hg * per_head;
+  const int head0 = hg * q.hloop, head1 = min(head0 + q.hloop, p.n_heads);
   const int b = rem / per_img;
   rem -= b * per_img;
   const int y0 = (rem / q.tiles_x) * HP_TH, x0 = (rem % q.tiles_x) * HP_TW;
-  const unsigned char* w1 = q.w_first[head];
 
   // ---- patch -> LDS (one pass, every load in flight before the first LDS write)
   {
@@ -924,7 +924,9 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
     const int t = min(4 * i + g, 8);
     pc_off[i] = ((t / 3) * HP_PW + t % 3) * ROWB + NS * 64;
   }
-  f32x4 acc[4][8];
+  __syncthreads();                           // the patch is complete
+  auto first_layer = [&](int head, f32x4 (&acc)[4][8]) __attribute__((always_inline)) {
+  const unsigned char* w1 = q.w_first[head];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -941,7 +943,6 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
     }
   };
   load_w(wh[0], wl[0], 0);
-  __syncthreads();
 
 #pragma unroll
   for (int ks = 0; ks < NK; ++ks) {
@@ -981,8 +982,12 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  };
 
-  if (p.n_hidden > 0) {
+  if (p.n_hidden > 0) {                      // (the host launches these with hloop == 1)
+    const int head = head0;
+    f32x4 acc[4][8];
+    first_layer(head, acc);
     // hidden layers need all 256 channels of a pixel: the two 64-pixel halves of the tile go through
     // the LDS-resident chain of cf_head_tail one after the other (LDS stays at 66 KiB: 2 workgroups/CU)
     __syncthreads();                         // every wave is done with the patch
@@ -1001,6 +1006,9 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
     return;
   }
 
+  for (int head = head0; head < head1; ++head) {
+  f32x4 acc[4][8];
+  first_layer(head, acc);
   // ---- output layer from registers: this wave's 64 hidden channels = 2 k-steps of 32
   f32x4 oacc[8];
 #pragma unroll
@@ -1034,9 +1042,8 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
       }
     }
   }
-  __syncthreads();                           // every wave is done with the patch: reuse LDS for the partial sums
   const int n_out = p.n_out[head], act = p.act[head];
-  float* red = reinterpret_cast<float*>(xt); // [wave][n 16][px 128]
+  float* red = reinterpret_cast<float*>(xt + hp16_patch_bytes(PC));   // [wave][n 16][px 128], BEHIND the patch (which the next head reuses)
 #pragma unroll
   for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
@@ -1064,6 +1071,8 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
       }
     }
   }
+  __syncthreads();                           // the partial sums are consumed: the next head may overwrite them
+  }                                          // head loop
 }
 
 }  // namespace
@@ -1175,13 +1184,29 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
     lim_plain.ensure(head_patch_kernel<4, false>, HP_LDS, HP_LDS);
     lim_pc.ensure(head_patch_kernel<4, true>, HP_LDS, HP_LDS);
     if (m16) {
+      // heads without hidden layers: a workgroup walks several heads on one patch (default: two ranges per launch -
+      // the patch is read twice instead of once per head, the grid keeps >= 10 rounds of workgroups; CF_HEAD_LOOP
+      // overrides for dev tools).  With hidden layers the chain rewrites the patch: one head per workgroup.
+      int hloop = 1;
+      if (a->tail.n_hidden == 0) {
+        hloop = (a->tail.n_heads + 1) / 2;
+        if (const char* e = getenv("CF_HEAD_LOOP")) hloop = atoi(e);
+        if (hloop < 1) hloop = 1;
+        if (hloop > a->tail.n_heads) hloop = a->tail.n_heads;
+      }
+      hp.hloop = hloop;
+      const long blocks16 = (long)hp.tiles_x * hp.tiles_y * a->tail.B * ((a->tail.n_heads + hloop - 1) / hloop);
       static CfLdsLimit lim16_plain, lim16_pc;
-      lim16_plain.ensure(head_patch16_kernel<4, false>, HP_LDS, HP_LDS);
-      lim16_pc.ensure(head_patch16_kernel<4, true>, HP_LDS, HP_LDS);
-      if (a->n_src == 2)
-        hipLaunchKernelGGL((head_patch16_kernel<4, true>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
-      else
-        hipLaunchKernelGGL((head_patch16_kernel<4, false>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
+      const bool hidden = a->tail.n_hidden > 0;
+      if (a->n_src == 2) {
+        const int lds = hp16_lds(true, hidden);
+        lim16_pc.ensure(head_patch16_kernel<4, true>, lds, hp16_lds(true, false));
+        hipLaunchKernelGGL((head_patch16_kernel<4, true>), dim3((unsigned)blocks16), dim3(256), lds, (hipStream_t)stream, hp);
+      } else {
+        const int lds = hp16_lds(false, hidden);
+        lim16_plain.ensure(head_patch16_kernel<4, false>, lds, hp16_lds(false, false));
+        hipLaunchKernelGGL((head_patch16_kernel<4, false>), dim3((unsigned)blocks16), dim3(256), lds, (hipStream_t)stream, hp);
+      }
       return cf_check_launch("cf_head_fused");
     }
     if (a->n_src == 2)

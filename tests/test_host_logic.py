@@ -201,3 +201,15 @@ def test_reference_loader_accepts_our_module():
             if k not in saved_mods:
                 del sys.modules[k]
         sys.modules.update(saved_mods)
+
+
+def test_no_exec_masked_prefetch_in_pinned_loops():
+    """the scheduling-pinned MFMA loops hold no exec-masked operand load (tools/check_isa.py
+    compiles the kernels to gfx950 assembly - no GPU needed - and scans them)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "conv3x3_f16x3_kernel" in r.stdout and "head_patch16_kernel" in r.stdout

@@ -15,9 +15,16 @@ if not path.endswith(".db"):
     path = max(glob.glob(path + "/**/*.db", recursive=True), key=os.path.getmtime)
 c = sqlite3.connect(path)
 rows = list(c.execute("select name, start, end from kernels order by start"))
-first = next(k for k in ("stem_kernel", "nchw_to_nhwc4") if any(k in r[0] for r in rows))
-marks = [i for i, r in enumerate(rows) if first in r[0]]
-last = rows[marks[-2]:marks[-1]]
+# a step ENDS with the decode kernel (one per step on every stream configuration; with model.streams > 1 a step holds
+# one stem launch per trunk stream, so the stem cannot delimit it)
+enders = ("decode_post_kernel", "decode_gather_kernel")
+ends = [i for i, r in enumerate(rows) if any(e in r[0] for e in enders)]
+if len(ends) >= 2:
+    last = rows[ends[-2] + 1:ends[-1] + 1]
+else:
+    first = next(k for k in ("stem_kernel", "nchw_to_nhwc4") if any(k in r[0] for r in rows))
+    marks = [i for i, r in enumerate(rows) if first in r[0]]
+    last = rows[marks[-2]:marks[-1]]
 span = (last[-1][2] - last[0][1]) / 1e6
 busy = sum(e - s for _, s, e in last) / 1e6
 print(f"{len(rows)} launches in the trace, {len(last)} per step; one steady-state step: span {span:.3f} ms, kernel-busy {busy:.3f} ms")
