@@ -35,8 +35,8 @@ def violations(lines):
         l = lines[i]
         if "s_and_saveexec" in l:
             masked = True
-        elif re.search(r"s_or_b64\s+exec", l) or re.search(r"s_mov_b64\s+exec", l):
-            masked = False
+        elif re.search(r"s_or_b64\s+exec", l) or re.search(r"s_mov_b64\s+exec", l) or "s_endpgm" in l or re.search(r"\bs_branch\b", l):
+            masked = False                    # (straight-line tracking: a return or an unconditional branch ends the masked fall-through)
         elif masked and re.search(r"\b(global|buffer|flat)_load_dwordx[234]", l):     # operand-class (prefetch) loads
             bad.append((i, l.strip()))
     return bad
