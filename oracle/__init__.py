@@ -15,7 +15,12 @@ Pinning status (see DESIGN.md "Oracle"):
     /root/reference and from this image, version not pinned by the reference):
     PARITY UNPINNED - restated from torchvision's documented semantics and
     held by known-answer tests only (tests/test_oracle_dcn.py).
-  * pillar expansion (reference module cannot be imported: cv2 / pycocotools /
-    lightning at module top): PARITY UNPINNED - restated from the source text
-    and held by hand-computable cases + property tests.
+  * pillar expansion, radar ingest, nuScenes result serialisation: PINNED by
+    fixtures generated from the reference's own dataset classes
+    (tests/golden/make_golden_dataset.py; arithmetic stand-ins for absent
+    libraries: cv2.transform / getAffineTransform, devkit view_points - stated
+    in the generator); bit-exact.  The orientation quaternion of the result
+    file (pyquaternion / devkit Box, absent) alone is restated, unpinned.
+  * image pre-processing (cv2.warpAffine, absent): PARITY UNPINNED - restated
+    from OpenCV's published fixed-point algorithm, held by known-answer tests.
 """
