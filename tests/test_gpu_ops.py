@@ -590,7 +590,11 @@ def test_conv2d_f16x3_root_concat(dev):
 
 @pytest.mark.parametrize("B,Ci,Co,H,W,mag", [(2, 64, 64, 28, 50, 2.0), (1, 128, 64, 14, 25, 8.0),
                                              (1, 512, 256, 7, 13, 1.0), (2, 256, 128, 9, 11, 30.0),
-                                             (1, 128, 128, 20, 23, 3.0)])
+                                             (1, 128, 128, 20, 23, 3.0),
+                                             # 64 outputs on maps without K split: ragged pixel tiles, offsets of
+                                             # 0.5 / 1.5 / 12 px (far outside any local window), 48 of 64 output rows used
+                                             (1, 64, 64, 37, 70, 0.5), (2, 128, 64, 33, 52, 1.5), (1, 64, 64, 48, 64, 12.0),
+                                             (1, 32, 48, 50, 45, 1.0)])
 def test_dcn_v2_f16x3(dev, B, Ci, Co, H, W, mag):
     from centerfusiondetect3d_amd import ops, packing
     x = rnd(B, Ci, H, W, seed=1)
