@@ -53,6 +53,13 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int wk = wave % WK, wp = (wave / WK) % WP, wc = wave / (WK * WP);
+#ifdef CF_CONV3_PROF   // dev (tools/prof_conv3.py): cycles per phase of thread 0, written over its first output values
+  long long t_prof[4] = {0, 0, 0, 0};
+  long long t_last = clock64();
+#define PROF_MARK(i) { const long long t_now = clock64(); t_prof[i] += t_now - t_last; t_last = t_now; }
+#else
+#define PROF_MARK(i)
+#endif
   // consecutive tiles on ONE XCD (cf_xcd_remap): neighbouring patches overlap, and every round
   // re-touches the same rows - both should hit that XCD's L2
   const int bid = cf_xcd_remap(blockIdx.x, gridDim.x);
@@ -174,6 +181,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
   for (int t = 0; t < 3; ++t) load_w(wh[t], wl[t], wk * 9 + t);
   store_patch(smem, 0, NU);
   __syncthreads();
+  PROF_MARK(0)
 
   for (int r = 0; r < p.n_rounds; ++r) {
     const unsigned char* cur = smem + (DB ? (r & 1) * bufb : 0);
@@ -223,6 +231,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    PROF_MARK(1)
     if (!DB) {
       __syncthreads();                       // single buffer: everyone is done reading it
       if (more) {
@@ -232,6 +241,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     }
     if (more) store_patch(nxt, NH0, NU);
     __syncthreads();
+    PROF_MARK(2)
   }
 
   // ---- K-split waves: partial sums -> LDS, added by wave wk == 0 in fixed order
@@ -262,9 +272,72 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
         }
   }
 
-  // ---- epilogue: lane = pixel, register group g = 4 consecutive channels
+  // ---- epilogue, coalesced form: the accumulators hold 4 consecutive channels of 32 DIFFERENT pixels per register
+  // group, so storing them directly writes 32-byte pieces 64 channels apart (and reads the residual the same way) -
+  // measured 8-26 % of a workgroup's time in this phase.  Each wave transposes its 32 pixels x 32*RT channels through
+  // a private LDS tile instead (LDS executes a wave's instructions in order: no barrier) and then writes / reads whole
+  // pixel rows: 16*... lanes cover one contiguous run of RT*128 bytes.
+  constexpr bool coalesced = WK == 1 && NT == 256;   // (8-wave configuration: measured no better; K-split waves: direct)
+  if (coalesced && w_ok) {
+    constexpr int EROW = RT * 128 + 16;      // bytes per pixel row of the tile: +16 B so that 16 lanes hit 64 banks
+    constexpr int LPP = RT * 8;              // lanes (16-byte chunks) per pixel
+    constexpr int PPI = 64 / LPP;            // pixels per instruction
+    unsigned char* eb = smem + wave * 32 * EROW;
+    const int chunk = lane % LPP, psub = lane / LPP;
+    const int n = rt0 * 32 + chunk * 4;
+    const bool n_ok = n < p.N;
+    f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n + e < p.N) bias4[e] = p.bias[n + e];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
+          *reinterpret_cast<f32x4*>(eb + li * EROW + (rt * 32 + 8 * g + 4 * h) * 4) = v;
+        }
+#pragma unroll
+      for (int it = 0; it < 32 / PPI; ++it) {
+        const int ploc = it * PPI + psub;
+        const int pl = wp * 64 + ct * 32 + ploc;
+        int m = m0 + pl;
+        bool ok = n_ok;
+        if (T2) {
+          const int y = ty0 + (pl >> 4), x = tx0 + (pl & 15);
+          ok = ok && y < p.H && x < p.W;
+          m = m0 + y * p.W + x;
+        } else {
+          ok = ok && m < p.M;
+        }
+        f32x4 v = *reinterpret_cast<const f32x4*>(eb + ploc * EROW + chunk * 16) + bias4;
+        if (ok && n + 3 < p.N) {
+          if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.res_stride + n);
+          if (p.act == CF_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+          }
+          *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.out_stride + n) = v;
+        } else if (ok) {                     // last, partial group of channels (N = 27): element by element
+          for (int e = 0; e < 4 && n + e < p.N; ++e) {
+            float x = v[e];
+            if (p.residual) x += p.residual[(size_t)m * p.res_stride + n + e];
+            if (p.act == CF_ACT_RELU) x = fmaxf(x, 0.0f);
+            p.out[(size_t)m * p.out_stride + n + e] = x;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue, direct form (K-split waves, N not a multiple of 4): lane = pixel, register group g = 4 consecutive channels
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
+    if (coalesced) break;
     const int pl = wp * 64 + ct * 32 + li;
     int m = m0 + pl;
     if (T2) {
@@ -301,6 +374,15 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
         }
       }
   }
+#ifdef CF_CONV3_PROF
+  PROF_MARK(3)
+  if (tid == 0 && blockIdx.y == 0) {
+    const int pl = 0;
+    size_t m = m0 + pl;
+    if (T2) m = m0 + (size_t)ty0 * p.W + tx0;
+    for (int i = 0; i < 4; ++i) p.out[m * p.out_stride + i] = (float)t_prof[i];
+  }
+#endif
 }
 
 template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2 = false>
@@ -321,6 +403,8 @@ bool try_launch(Conv3F k, int batch, hipStream_t st) {
   if (units > (long)NT * NU || blocks >= (1L << 31)) return false;
   size_t dyn = (size_t)(DB ? 2 : 1) * (k.PR + 1) * ROWB;
   if (WK > 1) dyn = dyn < (size_t)4 * RT * 2 * 16 * 64 * 4 ? (size_t)4 * RT * 2 * 16 * 64 * 4 : dyn;
+  constexpr size_t epi = (size_t)(64 * WC * WP * WK / 64) * 32 * (RT * 128 + 16);   // the waves' transposition tiles
+  if (WK == 1 && NT == 256 && dyn < epi) dyn = epi;
   if (dyn > 160 * 1024) return false;
   auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB, T2>;
   static CfLdsLimit lds_limit;                // (one per template instantiation)

@@ -21,6 +21,7 @@
 // per 32-deep chunk.  Workgroup = 4 waves as WC (channel groups) x WP (pixel groups); a wave owns
 // RT*32 output channels x 64 pixels.  Accumulators have pixels on lanes and 4 consecutive channels
 // per register group, so the fp32 NHWC store is one 16-byte write per lane and group.
+#include <stdlib.h>
 #include "cf_f16x3.h"
 
 namespace {
@@ -45,7 +46,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvF p) {
   constexpr int PXB = 64 * WP;             // pixels per workgroup
   constexpr int PLANE = PXB * FROWB;       // bytes per plane of one chunk buffer
   constexpr int BUF = 2 * PLANE;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(DB ? 2 : 1) * BUF];
+  constexpr int EROW = RT * 128 + 16;      // epilogue: a wave's 32 pixels x 32*RT channels, transposed through LDS
+  constexpr int SMEM = (DB ? 2 : 1) * BUF > 4 * 32 * EROW ? (DB ? 2 : 1) * BUF : 4 * 32 * EROW;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   extern __shared__ __attribute__((aligned(16))) cf_slot lds_slots[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -178,37 +181,51 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvF p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane = pixel, register group g = 4 consecutive channels
+  // ---- epilogue, coalesced (see cf_conv3x3_f16.hip): each wave transposes its 32 pixels x 32*RT channels through a
+  // private LDS tile (free after the loop's last barrier) and stores / reads the residual as whole pixel rows
+  if (w_ok) {
+    constexpr int LPP = RT * 8, PPI = 64 / LPP;
+    unsigned char* eb = smem + wave * 32 * EROW;
+    const int chunk = lane % LPP, psub = lane / LPP;
+    const int n = rt0 * 32 + chunk * 4;
+    f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int m = m0 + wp * 64 + ct * 32 + li;
-    if (m >= p.M) continue;
+    for (int e = 0; e < 4; ++e)
+      if (n + e < p.N) bias4[e] = p.bias[n + e];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = (rt0 + rt) * 32 + 8 * g + 4 * h;
-        if (n >= p.N) continue;
-        f32x4 v;
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
+          *reinterpret_cast<f32x4*>(eb + li * EROW + (rt * 32 + 8 * g + 4 * h) * 4) = v;
+        }
+#pragma unroll
+      for (int it = 0; it < 32 / PPI; ++it) {
+        const int ploc = it * PPI + psub;
+        const size_t m = (size_t)m0 + wp * 64 + ct * 32 + ploc;
+        f32x4 v = *reinterpret_cast<const f32x4*>(eb + ploc * EROW + chunk * 16) + bias4;
+        if (m >= (size_t)p.M || n >= p.N) continue;
         if (n + 3 < p.N) {
-          v += *reinterpret_cast<const f32x4*>(p.bias + n);
-          if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.res_stride + n);
+          if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + m * p.res_stride + n);
           if (p.act == CF_ACT_RELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
           }
-          *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.out_stride + n) = v;
-        } else {
+          *reinterpret_cast<f32x4*>(p.out + m * p.out_stride + n) = v;
+        } else {                             // last, partial group of channels: element by element
           for (int e = 0; e < 4 && n + e < p.N; ++e) {
-            float x = v[e] + p.bias[n + e];
-            if (p.residual) x += p.residual[(size_t)m * p.res_stride + n + e];
+            float x = v[e];
+            if (p.residual) x += p.residual[m * p.res_stride + n + e];
             if (p.act == CF_ACT_RELU) x = fmaxf(x, 0.0f);
-            p.out[(size_t)m * p.out_stride + n + e] = x;
+            p.out[m * p.out_stride + n + e] = x;
           }
         }
       }
+    }
   }
 }
 
@@ -230,9 +247,10 @@ struct DcnF {
   unsigned* out_split;   // optional split-bf16 copy [M][2][split_stride] (as 32-bit words: 2 bf16 each)
   int split_stride;
   float* partial;        // K split (gridDim.z > 1): raw partial sums [z][M][n_rt * 32], reduced by dcn_reduce_kernel
+  int direct_epilogue;   // dev A/B (CF_DCN_EPI=0): store the accumulators directly
 };
 
-template <int WC, int WP, int RT>
+template <int WC, int WP, int RT, bool COAL>
 __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   static_assert(WC * WP == 4, "4 waves per workgroup");
   constexpr int PXB = 64 * WP;
@@ -448,9 +466,63 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     return;
   }
 
+  // Coalesced epilogue (as in cf_conv3x3_f16.hip): each wave transposes its 32 pixels x 32*RT channels through a private
+  // LDS tile (free after the loop's last barrier) and writes whole pixel rows - RT*128 contiguous bytes per pixel
+  // instead of 32-byte pieces - and the split-bf16 copy as 8-byte pieces that are contiguous across lanes.
+  constexpr bool coalesced = COAL;        // (the host selects it: N % 4 == 0)
+  if (coalesced && w_ok) {
+    constexpr int EROW = RT * 128 + 16;
+    constexpr int LPP = RT * 8, PPI = 64 / LPP;
+    unsigned char* eb = smem + wave * 32 * EROW;
+    const int chunk = lane % LPP, psub = lane / LPP;
+    const int n = rt0 * 32 + chunk * 4;
+    const bool n_ok = n < p.N;
+    f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (n_ok) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
+          *reinterpret_cast<f32x4*>(eb + li * EROW + (rt * 32 + 8 * g + 4 * h) * 4) = v;
+        }
+#pragma unroll
+      for (int it = 0; it < 32 / PPI; ++it) {
+        const int ploc = it * PPI + psub;
+        const size_t m = (size_t)m0 + wp * 64 + ct * 32 + ploc;
+        f32x4 v = *reinterpret_cast<const f32x4*>(eb + ploc * EROW + chunk * 16) + bias4;
+        if (n_ok && m < (size_t)p.M) {
+          if (p.act == CF_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+          }
+          *reinterpret_cast<f32x4*>(p.out + m * p.out_stride + n) = v;
+          if (p.out_split) {   // hi = rne_bf16(v), lo = rne_bf16(v - hi): the head kernels' input format
+            unsigned w[4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const __bf16 h0 = (__bf16)v[2 * e], h1 = (__bf16)v[2 * e + 1];
+              const __bf16 l0 = (__bf16)(v[2 * e] - (float)h0), l1 = (__bf16)(v[2 * e + 1] - (float)h1);
+              w[e] = ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16) | __builtin_bit_cast(unsigned short, h0);
+              w[2 + e] = ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16) | __builtin_bit_cast(unsigned short, l0);
+            }
+            unsigned* o = p.out_split + (m * 2 * p.split_stride + n) / 2;
+            *reinterpret_cast<uint2*>(o) = uint2{w[0], w[1]};
+            *reinterpret_cast<uint2*>(o + p.split_stride / 2) = uint2{w[2], w[3]};
+          }
+        }
+      }
+    }
+  }
+
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     const int m = m0 + wp * 64 + ct * 32 + li;
+    if (coalesced) break;
     if (m >= p.M) continue;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -605,12 +677,21 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   const unsigned ks = a->workspace ? (unsigned)dcn_k_split(a->H, a->W, k.n_chunks, a->N_pad) : 1u;
   CF_REQUIRE(ks == 1 || !a->out_split_bf16, "cf_dcn_v2_f16x3: the split-bf16 output is not available on K-split maps");
   k.partial = static_cast<float*>(a->workspace);
+  static const int direct_epi = [] { const char* e = getenv("CF_DCN_EPI"); return e ? atoi(e) == 0 : 0; }();
+  k.direct_epilogue = direct_epi;
+  const bool coal = (a->N & 3) == 0 && !k.direct_epilogue;   // whole-row epilogue through LDS
   if (a->N_pad <= 64) {          // 64 channels: 2 x 32-channel wave rows, 2 x 64 pixels
-    launch_f16(dcn_f16x3_kernel<2, 2, 1>, dim3((unsigned)((M + 127) / 128), (unsigned)((a->N_pad + 63) / 64), ks), 0, st, k);
+    const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((a->N_pad + 63) / 64), ks);
+    if (coal) launch_f16(dcn_f16x3_kernel<2, 2, 1, true>, grid, 0, st, k);
+    else launch_f16(dcn_f16x3_kernel<2, 2, 1, false>, grid, 0, st, k);
   } else if (a->N_pad <= 128) {  // 128 channels: 4 x 32-channel wave rows, 64 pixels
-    launch_f16(dcn_f16x3_kernel<4, 1, 1>, dim3((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 127) / 128), ks), 0, st, k);
+    const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 127) / 128), ks);
+    if (coal) launch_f16(dcn_f16x3_kernel<4, 1, 1, true>, grid, 0, st, k);
+    else launch_f16(dcn_f16x3_kernel<4, 1, 1, false>, grid, 0, st, k);
   } else {
-    launch_f16(dcn_f16x3_kernel<4, 1, 2>, dim3((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 255) / 256), ks), 0, st, k);
+    const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 255) / 256), ks);
+    if (coal) launch_f16(dcn_f16x3_kernel<4, 1, 2, true>, grid, 0, st, k);
+    else launch_f16(dcn_f16x3_kernel<4, 1, 2, false>, grid, 0, st, k);
   }
   if (ks > 1) {
     const int ns4 = k.n_rt * 32 / 4;
