@@ -651,6 +651,7 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   CF_REQUIRE(a != nullptr, "cf_dcn_v2_f16x3: null args");
   CF_REQUIRE(a->C > 0 && a->C % 32 == 0, "cf_dcn_v2_f16x3: C=%d not a multiple of 32", a->C);
   CF_REQUIRE(a->N > 0 && a->N_pad >= a->N && a->N_pad % 32 == 0, "cf_dcn_v2_f16x3: N=%d N_pad=%d", a->N, a->N_pad);
+  CF_REQUIRE(a->N_pad <= 128 || a->N_pad % 64 == 0, "cf_dcn_v2_f16x3: N_pad=%d above 128 must be a multiple of 64 (two row tiles per wave)", a->N_pad);
   CF_REQUIRE(a->om_stride >= 27, "cf_dcn_v2_f16x3: om_stride=%d < 27", a->om_stride);
   CF_REQUIRE(a->x && a->offmask && a->weight && a->bias && a->out, "cf_dcn_v2_f16x3: null buffer");
   CF_REQUIRE(a->out_stride >= a->N && a->out_stride % 4 == 0, "cf_dcn_v2_f16x3: bad out_stride");

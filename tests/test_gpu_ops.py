@@ -622,6 +622,15 @@ def test_dcn_v2_f16x3(dev, B, Ci, Co, H, W, mag):
     assert torch.equal(out2, ops.dcn_v2_fused(pd, nhwc(x).to(dev), om32.to(dev), k_split=False))
 
 
+def test_dcn_v2_f16x3_rejects_odd_tile_counts_above_128(dev):
+    """N_pad = 160 would give the two-row-tiles-per-wave kernel a tile past the packed weights: refused, not run."""
+    from centerfusiondetect3d_amd import ops, packing, _lib
+    B, Ci, Co, H, W = 1, 32, 160, 8, 8
+    pd = packing.pack_dcn_f16(rnd(Co, Ci, 3, 3, seed=3), rnd(Co, seed=4)).to(dev)
+    with pytest.raises(_lib.CfHipError):
+        ops.dcn_v2_fused(pd, torch.zeros(B, H, W, Ci, device=dev), torch.zeros(B, H, W, 32, device=dev))
+
+
 # ----------------------------------------------------------------------------------- fused stem
 @pytest.mark.parametrize("B,C,H,W", [(2, 3, 64, 96), (1, 3, 16, 16), (1, 3, 34, 50), (3, 1, 18, 130), (1, 3, 160, 224)])
 def test_stem_fused(dev, B, C, H, W):
