@@ -210,6 +210,36 @@ def end_to_end(args, dev, model):
                                             "pcie_bytes_per_frame": 900 * 1600 * 3}}
 
 
+def other_configs(dev, steps=12):
+    """BASELINE.json's other single-GPU configurations on the same build, a few steps each (rank 0, N=1, default run
+    only): C4 (offsets O(8 px)), C5 (3x896x1600, bs=8), one-frame latency.  Parity for each: tests/test_gpu_model.py."""
+    from centerfusiondetect3d_amd import getModel, centerfusion_middle_config, decode_post_packed
+    from centerfusiondetect3d_amd.postprocess import inverse_affine_device
+    out = {}
+
+    def measure(B, H, W, offset_std):
+        model = synthetic_weights(getModel(centerfusion_middle_config((H, W))), seed=0, offset_std=offset_std).to(dev).eval()
+        images, pc_dep, calib = make_inputs(B, H, W, dev, seed=2000)
+        tinv = inverse_affine_device(np.array([800.0, 450.0], np.float32), 1600.0, (W // 4, H // 4), dev)
+        with torch.no_grad():
+            for _ in range(6):
+                decode_post_packed(model(images, pc_dep=pc_dep, calib=calib), calib, tinv, (H // 4, W // 4), 100)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                decode_post_packed(model(images, pc_dep=pc_dep, calib=calib), calib, tinv, (H // 4, W // 4), 100)
+            torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        del model, images, pc_dep, calib
+        torch.cuda.empty_cache()
+        return {"ms_per_step": round(ms, 3), "frames_per_s": round(B / ms * 1e3, 1), "batch": B, "input": f"3x{H}x{W}"}
+
+    out["C4_dcn_offsets_8px"] = measure(16, 448, 800, 0.04)
+    out["C5_highres"] = measure(8, 896, 1600, 0.01)
+    out["C2_single_frame_latency"] = measure(1, 448, 800, 0.01)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -353,7 +383,12 @@ def main():
                          "flop_per_launch": launch_flops, "avg_launch_ms": round(avg_ms, 4),
                          "launches_timed": len(launch_ms)},
         }
+        default_run = (B, H, W) == (16, 448, 800) and not args.exact_fp32 and args.offset_std == 0.01
         if not args.no_cpu_baseline and world == 1:
+            if default_run:
+                del images, pc_dep
+                torch.cuda.empty_cache()
+                result["other_configs"] = other_configs(dev)
             result["cpu_baseline"] = cpu_baseline(H, W, batch=B)
         elif world == 1:
             result["cpu_baseline"] = None
