@@ -121,10 +121,10 @@ struct FlatMap {       // 64 consecutive pixels of the flattened (B*H*W) index s
     return true;
   }
 };
-struct TileMap {       // rows [4 half, 4 half + 4) of an 8 x 16 tile at (y0, x0) of image b
-  int b, y0, x0, H, W;
+struct TileMap {       // 64 pixels of a tile at (y0, x0) of image b: 4 rows of 16 (sh = 4) or 8 rows of 8 (sh = 3)
+  int b, y0, x0, H, W, sh = 4;
   __device__ __forceinline__ bool operator()(int px, int& bb, int& pix) const {
-    const int y = y0 + (px >> 4), x = x0 + (px & 15);
+    const int y = y0 + (px >> sh), x = x0 + (px & ((1 << sh) - 1));
     if (y >= H || x >= W) return false;
     bb = b;
     pix = y * W + x;
@@ -855,9 +855,14 @@ __global__ __launch_bounds__(256, 2) void head_patch_kernel(HeadPatchK q) {
 // tiles give a lane 4 + 4 channels of one pixel = one B fragment, with w_out packed in that k order
 // (pack_fragments16(acc_order=True)); n_out <= 16.
 // ---------------------------------------------------------------------------------------------
-template <int NS, bool PC>
+template <int NS, bool PC, bool TP>
 __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   static_assert(NS == 4, "64 feature channels");
+  // TP: the 128-pixel tile stands upright (16 rows x 8 columns) instead of 8 x 16 - same patch size (18 x 10 rows), chosen by
+  // the host when it covers the map with fewer tiles (112 x 200: 7 x 25 = 175 exact tiles instead of 14 x 13 = 182)
+  constexpr int TSH = TP ? 3 : 4, TMASK = (1 << TSH) - 1;          // pixel index -> (row = px >> TSH, column = px & TMASK)
+  constexpr int T_H = TP ? 16 : 8, T_W = TP ? 8 : 16, P_W = T_W + 2;
+  static_assert((T_H + 2) * P_W == HP_ROWS, "both tile shapes have the same patch size");
   constexpr int ROWB = NS * 64 + (PC ? 32 : 0) + 16;     // odd multiple of 16 B
   constexpr int NKF = 9 * NS / 2;                        // k32-steps of the feature channels
   constexpr int NK = NKF + (PC ? 3 : 0);
@@ -876,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   const int head0 = hg * q.hloop, head1 = min(head0 + q.hloop, p.n_heads);
   const int b = rem / per_img;
   rem -= b * per_img;
-  const int y0 = (rem / q.tiles_x) * HP_TH, x0 = (rem % q.tiles_x) * HP_TW;
+  const int y0 = (rem / q.tiles_x) * T_H, x0 = (rem % q.tiles_x) * T_W;
 
   // ---- patch -> LDS (one pass, every load in flight before the first LDS write)
   {
@@ -887,7 +892,7 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
     for (int it = 0; it < NIT; ++it) {
       const int idx = tid + it * 256;
       const int row = idx / UPR, u = idx % UPR;
-      const int y = y0 - 1 + row / HP_PW, x = x0 - 1 + row % HP_PW;
+      const int y = y0 - 1 + row / P_W, x = x0 - 1 + row % P_W;
       v[it] = u32x4{0u, 0u, 0u, 0u};
       if (row < HP_ROWS && (unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W)
         v[it] = *reinterpret_cast<const u32x4*>(q.src[0] + ((size_t)(b * p.HW + y * q.W + x) * 2 * q.src_c[0]) * 2 +
@@ -903,7 +908,7 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
     if (PC) {
       for (int idx = tid; idx < HP_ROWS * 2; idx += 256) {
         const int row = idx >> 1, plane = idx & 1;
-        const int y = y0 - 1 + row / HP_PW, x = x0 - 1 + row % HP_PW;
+        const int y = y0 - 1 + row / P_W, x = x0 - 1 + row % P_W;
         u32x4 w = {0u, 0u, 0u, 0u};
         if ((unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W)
           w = *reinterpret_cast<const u32x4*>(q.src[1] + ((size_t)(b * p.HW + y * q.W + x) * 2 + plane) * q.src_c[1] * 2);
@@ -916,13 +921,14 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   // k-step's 32 for pixel column c of the 16-pixel tile row
   int rowb[8];                               // LDS byte offset of this lane's pixel in tile row ct (tap (-1,-1))
 #pragma unroll
-  for (int ct = 0; ct < 8; ++ct) rowb[ct] = (ct * HP_PW + c16) * ROWB;
+  for (int ct = 0; ct < 8; ++ct)          // pixel ct * 16 + c16: a compile-time stride per ct (immediate offsets of the ds_reads)
+    rowb[ct] = ((c16 >> TSH) * P_W + (c16 & TMASK)) * ROWB + ct * ((16 >> TSH) * P_W * ROWB);
   const int koff = (g >> 1) * 64 + (g & 1) * 16;         // 8-channel group inside a 32-channel half (hi plane; lo at +32)
   int pc_off[3];                             // pc_hm steps: k-group g of step i is tap 4i + g (taps 9..11: zero weights)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int t = min(4 * i + g, 8);
-    pc_off[i] = ((t / 3) * HP_PW + t % 3) * ROWB + NS * 64;
+    pc_off[i] = ((t / 3) * P_W + t % 3) * ROWB + NS * 64;
   }
   __syncthreads();                           // the patch is complete
   auto first_layer = [&](int head, f32x4 (&acc)[4][8]) __attribute__((always_inline)) {
@@ -950,7 +956,7 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
     int off, lo;
     if (ks < NKF) {
       const int tap = ks / (NS / 2), half = ks % (NS / 2);
-      off = ((tap / 3) * HP_PW + tap % 3) * ROWB + half * 128 + koff;
+      off = ((tap / 3) * P_W + tap % 3) * ROWB + half * 128 + koff;
       lo = 32;
     } else {
       off = pc_off[ks - NKF < 3 ? ks - NKF : 0];
@@ -1000,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
         for (int ct = 0; ct < 4; ++ct) a2[rt][ct] = acc[rt][4 * half + ct];
       store_hidden_tile16(xt, a2, q.b_first[head], wave, lane);
       __syncthreads();
-      head_tail_from_lds16(p, xt, head, TileMap{b, y0 + 4 * half, x0, q.H, q.W});
+      head_tail_from_lds16(p, xt, head, TileMap{b, y0 + (64 >> TSH) * half, x0, q.H, q.W, TSH});
       __syncthreads();
     }
     return;
@@ -1054,7 +1060,7 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   __syncthreads();
   {
     const int px = tid & (HP_PX - 1);
-    const int y = y0 + (px >> 4), x = x0 + (px & 15);
+    const int y = y0 + (px >> TSH), x = x0 + (px & TMASK);
     if (y < q.H && x < q.W) {
       const float* bo = p.b_out[head];
       float* out = p.out[head];
@@ -1195,18 +1201,28 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
         if (hloop > a->tail.n_heads) hloop = a->tail.n_heads;
       }
       hp.hloop = hloop;
-      const long blocks16 = (long)hp.tiles_x * hp.tiles_y * a->tail.B * ((a->tail.n_heads + hloop - 1) / hloop);
-      static CfLdsLimit lim16_plain, lim16_pc;
-      const bool hidden = a->tail.n_hidden > 0;
-      if (a->n_src == 2) {
-        const int lds = hp16_lds(true, hidden);
-        lim16_pc.ensure(head_patch16_kernel<4, true>, lds, hp16_lds(true, false));
-        hipLaunchKernelGGL((head_patch16_kernel<4, true>), dim3((unsigned)blocks16), dim3(256), lds, (hipStream_t)stream, hp);
-      } else {
-        const int lds = hp16_lds(false, hidden);
-        lim16_plain.ensure(head_patch16_kernel<4, false>, lds, hp16_lds(false, false));
-        hipLaunchKernelGGL((head_patch16_kernel<4, false>), dim3((unsigned)blocks16), dim3(256), lds, (hipStream_t)stream, hp);
+      // tile orientation: 8 x 16 or 16 x 8 pixels, whichever covers the map with fewer tiles (results do not depend on it;
+      // CF_HEAD_TILE = 0 / 1 forces one for dev tools)
+      const long t_land = (long)((k.W + 15) / 16) * ((k.H + 7) / 8), t_port = (long)((k.W + 7) / 8) * ((k.H + 15) / 16);
+      bool portrait = t_port < t_land;
+      if (const char* e = getenv("CF_HEAD_TILE")) portrait = atoi(e) != 0;
+      if (portrait) {
+        hp.tiles_x = (k.W + 7) / 8;
+        hp.tiles_y = (k.H + 15) / 16;
       }
+      const long blocks16 = (long)hp.tiles_x * hp.tiles_y * a->tail.B * ((a->tail.n_heads + hloop - 1) / hloop);
+      const bool hidden = a->tail.n_hidden > 0;
+      const bool pc = a->n_src == 2;
+      const int lds = hp16_lds(pc, hidden);
+      auto launch = [&](auto kernel, CfLdsLimit& lim) {
+        lim.ensure(kernel, lds, hp16_lds(pc, false));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)blocks16), dim3(256), lds, (hipStream_t)stream, hp);
+      };
+      static CfLdsLimit lim16[4];
+      if (pc && portrait) launch(head_patch16_kernel<4, true, true>, lim16[3]);
+      else if (pc) launch(head_patch16_kernel<4, true, false>, lim16[2]);
+      else if (portrait) launch(head_patch16_kernel<4, false, true>, lim16[1]);
+      else launch(head_patch16_kernel<4, false, false>, lim16[0]);
       return cf_check_launch("cf_head_fused");
     }
     if (a->n_src == 2)

@@ -460,6 +460,23 @@ def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W, patch):
         refs.append(raw)
     f = ops.head_fused_args(srcs, [s.shape[-1] for s in srcs], slots, k_pad, B, H, W, heads)
     assert f.layout3x3 == int(patch) and f.mfma16 == int(m16)
+    if m16:
+        # the 128-pixel tile lies flat (8 x 16) or stands upright (16 x 8), whichever needs fewer tiles: force both,
+        # the results must not differ by a bit
+        firsts = None
+        for tile in ("0", "1"):
+            os.environ["CF_HEAD_TILE"] = tile
+            try:
+                for hd in heads:
+                    hd["out"].fill_(float("nan"))
+                ops.run_head_fused(f)
+            finally:
+                del os.environ["CF_HEAD_TILE"]
+            outs = [hd["out"].clone() for hd in heads] + [hd["out2"].clone() for hd in heads if hd["out2"] is not None]
+            if firsts is None:
+                firsts = outs
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(firsts, outs))
     ops.run_head_fused(f)
     for hd, raw in zip(heads, refs):
         scale = float(raw.abs().max())
