@@ -275,18 +275,40 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   const bool w_ok = rt0 < p.n_rt;
   const int n_ks = p.n_chunks * 2;
   const int HW = p.H * p.W;
+#ifdef CF_DCN_PROF   // dev (tools/prof_dcn.py): cycles per phase of thread 0, written over its first output values
+  long long t_prof[4] = {0, 0, 0, 0};
+  long long t_last = clock64();
+#define DPROF_MARK(i) { const long long t_now = clock64(); t_prof[i] += t_now - t_last; t_last = t_now; }
+#else
+#define DPROF_MARK(i)
+#endif
 
-  for (int i = tid; i < PXB * 9; i += 256) {
+  // (all offset / mask values of the tile are requested before the first is used: one memory round trip for the phase
+  //  instead of one per descriptor - it was 13 % of a 64-channel layer's workgroup time)
+  constexpr int NDI = (PXB * 9 + 255) / 256;
+  float omy[NDI], omx[NDI], omm[NDI];
+#pragma unroll
+  for (int it = 0; it < NDI; ++it) {
+    const int i = min(tid + 256 * it, PXB * 9 - 1);
+    const int r = i / 9, tap = i - r * 9;
+    const float* om = p.om + (size_t)min(m0 + r, p.M - 1) * p.om_stride;
+    omy[it] = om[2 * tap];
+    omx[it] = om[2 * tap + 1];
+    omm[it] = om[18 + tap];
+  }
+#pragma unroll
+  for (int it = 0; it < NDI; ++it) {
+    const int i = tid + 256 * it;
+    if (i >= PXB * 9) break;
     const int r = i / 9, tap = i - r * 9;
     const int m = m0 + r;
     f32x4 dA = {0.0f, 0.0f, 0.0f, 0.0f}, dB = {0.0f, 0.0f, 0.0f, 0.0f};
     if (m < p.M) {
       const int b = m / HW, rem = m - b * HW;
       const int ho = rem / p.W, wo = rem - ho * p.W;
-      const float* om = p.om + (size_t)m * p.om_stride;
       const int ti = tap / 3, tj = tap - ti * 3;
-      const float hf = (float)(ho - 1 + ti) + om[2 * tap];
-      const float wf = (float)(wo - 1 + tj) + om[2 * tap + 1];
+      const float hf = (float)(ho - 1 + ti) + omy[it];
+      const float wf = (float)(wo - 1 + tj) + omx[it];
       const bool inside = hf > -1.0f && hf < (float)p.H && wf > -1.0f && wf < (float)p.W;
       const float hfl = floorf(hf), wfl = floorf(wf);
       const int hl = inside ? (int)hfl : 0, wl = inside ? (int)wfl : 0;
@@ -298,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
       dA[0] = __int_as_float(((b * p.H + y0) * p.W + x0) * p.C);
       dA[1] = __int_as_float((max(x1, x0) - x0) * p.C);
       dA[2] = __int_as_float((max(y1, y0) - y0) * p.W * p.C);
-      dA[3] = cf_sigmoid(om[18 + tap]) * ASCALE;
+      dA[3] = cf_sigmoid(omm[it]) * ASCALE;
       dB[0] = (t_ok && l_ok) ? hh * hw : 0.0f;
       dB[1] = (t_ok && r_ok) ? hh * lw : 0.0f;
       dB[2] = (b_ok && l_ok) ? lh * hw : 0.0f;
@@ -310,6 +332,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     desc[2 * i + 1] = dB;
   }
   __syncthreads();
+  DPROF_MARK(0)
 
   // corner samples are requested TWO chunks ahead (sets c & 1): the texture path, which bounds the
   // 64-channel layers, then always has a full chunk of requests queued behind the one being blended
@@ -446,6 +469,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     for (int j = 0; j < n_own; ++j) iteration(j, cvs[0], cws[0], cmks[0]);
   }
 
+  DPROF_MARK(1)
   if (gridDim.z > 1) {   // raw partial sums; scale / bias / activation happen in the reduction
     const int ns = p.n_rt * 32;
 #pragma unroll
@@ -562,6 +586,11 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
         }
       }
   }
+#ifdef CF_DCN_PROF
+  DPROF_MARK(2)
+  if (tid == 0 && blockIdx.y == 0 && m0 < p.M)
+    for (int i = 0; i < 3; ++i) p.out[(size_t)m0 * p.out_stride + i] = (float)t_prof[i];
+#endif
 }
 
 // K-split reduction: out = act((sum_z partial[z]) * out_scale + bias), partials added in z order
