@@ -1190,17 +1190,9 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
     lim_plain.ensure(head_patch_kernel<4, false>, HP_LDS, HP_LDS);
     lim_pc.ensure(head_patch_kernel<4, true>, HP_LDS, HP_LDS);
     if (m16) {
-      // heads without hidden layers: a workgroup walks several heads on one patch (default: two ranges per launch -
-      // the patch is read twice instead of once per head, the grid keeps >= 10 rounds of workgroups; CF_HEAD_LOOP
-      // overrides for dev tools).  With hidden layers the chain rewrites the patch: one head per workgroup.
+      // heads without hidden layers: a workgroup walks several heads on one patch (chosen below; CF_HEAD_LOOP overrides
+      // for dev tools).  With hidden layers the chain rewrites the patch: one head per workgroup.
       int hloop = 1;
-      if (a->tail.n_hidden == 0) {
-        hloop = (a->tail.n_heads + 1) / 2;
-        if (const char* e = getenv("CF_HEAD_LOOP")) hloop = atoi(e);
-        if (hloop < 1) hloop = 1;
-        if (hloop > a->tail.n_heads) hloop = a->tail.n_heads;
-      }
-      hp.hloop = hloop;
       // tile orientation: 8 x 16 or 16 x 8 pixels, whichever covers the map with fewer tiles (results do not depend on it;
       // CF_HEAD_TILE = 0 / 1 forces one for dev tools)
       const long t_land = (long)((k.W + 15) / 16) * ((k.H + 7) / 8), t_port = (long)((k.W + 7) / 8) * ((k.H + 15) / 16);
@@ -1210,6 +1202,28 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
         hp.tiles_x = (k.W + 7) / 8;
         hp.tiles_y = (k.H + 15) / 16;
       }
+      if (a->tail.n_hidden == 0) {
+        // heads per workgroup: 1, 2 or half of them, whichever needs the fewest rounds of (2 workgroups per CU) x (heads +
+        // a quarter of a head's time for the patch) - small batches want many short workgroups (bs=1: 103 vs 123 us with
+        // 1 vs 4 heads), bs=16 the long ones (1307 vs 1331 us).  The results do not depend on it.
+        static const int slots = [] {
+          int dev = 0, cus = 256;
+          if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+          return 2 * (cus > 0 ? cus : 256);
+        }();
+        const long tiles = (long)hp.tiles_x * hp.tiles_y * a->tail.B;
+        const int n = a->tail.n_heads, cand[3] = {1, 2, (n + 1) / 2};
+        double best = 0.0;
+        for (int i = 0; i < 3; ++i) {
+          const int h = cand[i] < 1 ? 1 : (cand[i] > n ? n : cand[i]);
+          const double cost = (double)((tiles * ((n + h - 1) / h) + slots - 1) / slots) * (h + 0.25);
+          if (i == 0 || cost < best - 1e-9) { best = cost; hloop = h; }
+        }
+        if (const char* e = getenv("CF_HEAD_LOOP")) hloop = atoi(e);
+        if (hloop < 1) hloop = 1;
+        if (hloop > n) hloop = n;
+      }
+      hp.hloop = hloop;
       const long blocks16 = (long)hp.tiles_x * hp.tiles_y * a->tail.B * ((a->tail.n_heads + hloop - 1) / hloop);
       const bool hidden = a->tail.n_hidden > 0;
       const bool pc = a->n_src == 2;
