@@ -41,11 +41,16 @@ DOMINANT = ["tails.primary", "tails.secondary"]
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
 
 
-def measured_traffic(kernels=("head_patch16_kernel<4, false>", "head_patch16_kernel<4, true>")):
-    """Average HBM-side bytes per launch over the dominant kernel's two instantiations."""
+def measured_traffic(prefixes=("head_patch16_kernel<4, false", "head_patch16_kernel<4, true")):
+    """Average HBM-side bytes per launch over the dominant kernel's two launches per step (primary heads: no pc_hm
+    source, secondary heads: with it; the third template argument is the tile orientation the host picked)."""
     try:
         t = json.load(open(TRAFFIC_FILE))
-        per = [t[k]["fetch_bytes_per_launch_x2_corrected"] + t[k]["write_bytes_per_launch"] for k in kernels]
+        per = []
+        for pre in prefixes:
+            ks = [k for k in t if k.startswith(pre)]
+            per.append(sum((t[k]["fetch_bytes_per_launch_x2_corrected"] + t[k]["write_bytes_per_launch"]) * t[k]["launches"]
+                           for k in ks) / sum(t[k]["launches"] for k in ks))
         return round(sum(per) / len(per))
     except Exception:
         return None

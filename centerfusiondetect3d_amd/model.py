@@ -151,6 +151,23 @@ def _param_spec(config) -> List[tuple]:
 
 
 # ----------------------------------------------------------------------------- execution plan
+_SIDE_STREAMS = {}    # (device, caller stream id) -> side streams, created once per PROCESS
+_SIDE_LOCK = __import__("threading").Lock()
+
+
+def _side_streams(device, sid, n):
+    """The n side streams that work issued on caller stream `sid` of `device` forks onto.  One set per process, not per
+    model or plan: HIP spreads streams over a few hardware queues in creation order, and whether two side streams share
+    a queue decides whether their kernels overlap at all - measured 8.5 vs 10.5 ms per bs=16 step for the FIRST vs the
+    SECOND pair of streams created in a process (10.6 ms also with GPU_MAX_HW_QUEUES=2).  Every model therefore forks onto the pair
+    the first model got."""
+    with _SIDE_LOCK:
+        pool = _SIDE_STREAMS.setdefault((str(device), int(sid)), [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device))
+        return pool[:n]
+
+
 class _Plan:
     """Buffers + pre-built launch list for one (B, H, W, device)."""
 
@@ -486,7 +503,7 @@ class _Plan:
             return
         cur = torch.cuda.current_stream(self.device)
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(self.device)
+            self._side = _side_streams(self.device, cur.cuda_stream, 1)[0]
             self._events = [torch.cuda.Event() for _ in range(self.n_events)]
         streams = (cur, self._side)
         ptrs = (st, self._side.cuda_stream)
@@ -611,7 +628,6 @@ class DLASeg(nn.Module):
         self.lanes = True        # small batches: the IDA projections on a side stream beside the node chain (_Plan.ida)
         self.streams = 2         # > 1 (and batch >= 4 * streams): backbone + neck as that many sub-batches on
                                  # concurrent HIP streams with their own plans; heads on the caller's stream
-        self._stream_pool = {}
         self.use_graph = False   # replay the forward as ONE captured HIP graph (inputs / outputs staged through
                                  # static buffers) instead of ~100 launches from Python (_forward_graph)
         self.stem_fused = True   # with conv_f16: base_layer + level0 + level1 in one launch (cf_stem.hip)
@@ -849,10 +865,7 @@ class DLASeg(nn.Module):
         k = B // n
         h4, w4 = H // 4, W // 4
         cur = torch.cuda.current_stream(dev)
-        pool = self._stream_pool.setdefault((dev, sid), [])
-        while len(pool) < n:
-            pool.append(torch.cuda.Stream(dev))
-        pool = pool[:n]
+        pool = _side_streams(dev, sid, n)
         hkey = (B, H, W, dev, sid, "heads")
         hplan = self._plans.get(hkey)
         bf = bool(self.heads_bf16)
