@@ -29,7 +29,10 @@ def run_single(streams):
 def run_threads(n_thr, stagger_ms):
     model.streams = 1
     shards = [(images[i::n_thr].contiguous(), pc_dep[i::n_thr].contiguous(), calib[i::n_thr].contiguous()) for i in range(n_thr)]
-    streams = [torch.cuda.Stream() for _ in range(n_thr)]
+    global _thread_streams
+    if "_thread_streams" not in globals():
+        _thread_streams = [torch.cuda.Stream() for _ in range(n_thr)]
+    streams = _thread_streams
     with torch.no_grad():
         for s, sh in zip(streams, shards):
             with torch.cuda.stream(s):
@@ -49,10 +52,14 @@ def run_threads(n_thr, stagger_ms):
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / K
 
-for s in (1, 2):
-    dt = run_single(s)
-    print(f"one thread, model.streams={s}: {dt * 1e3:.3f} ms per {B} frames = {B / dt:.0f} frames/s", flush=True)
-for n_thr in (2, 4):
-    for stg in (0.0, 2.0, 3.0):
-        dt = run_threads(n_thr, stg)
-        print(f"{n_thr} threads x {B // n_thr} frames, stagger {stg} ms: {dt * 1e3:.3f} ms per {B} frames = {B / dt:.0f} frames/s", flush=True)
+# (the first streams a process creates get their own hardware queues, later ones share: run the two modes in separate
+#  processes so that each measures with "first" streams:  ... 16 40 single   /   ... 16 40 threads)
+mode = sys.argv[3] if len(sys.argv) > 3 else "single"
+if mode == "single":
+    for s in (1, 2):
+        dt = run_single(s)
+        print(f"one thread, model.streams={s}: {dt * 1e3:.3f} ms per {B} frames = {B / dt:.0f} frames/s", flush=True)
+else:
+    for stg in (0.0, 1.0, 2.0, 3.0, 4.0):
+        dt = run_threads(2, stg)
+        print(f"2 threads x {B // 2} frames, stagger {stg} ms: {dt * 1e3:.3f} ms per {B} frames = {B / dt:.0f} frames/s", flush=True)
