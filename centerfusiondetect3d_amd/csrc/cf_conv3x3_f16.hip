@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
   // group, so storing them directly writes 32-byte pieces 64 channels apart (and reads the residual the same way) -
   // measured 8-26 % of a workgroup's time in this phase.  Each wave transposes its 32 pixels x 32*RT channels through
   // a private LDS tile instead (LDS executes a wave's instructions in order: no barrier) and then writes / reads whole
-  // pixel rows: 16*... lanes cover one contiguous run of RT*128 bytes.
+  // pixel rows: 8*RT lanes cover one contiguous run of RT*128 bytes.
   constexpr bool coalesced = WK == 1 && NT == 256;   // (8-wave configuration: measured no better; K-split waves: direct)
   if (coalesced && w_ok) {
     constexpr int EROW = RT * 128 + 16;      // bytes per pixel row of the tile: +16 B so that 16 lanes hit 64 banks
