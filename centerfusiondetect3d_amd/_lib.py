@@ -28,7 +28,8 @@ class DcnArgs(C.Structure):
                 ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("weight", _f), ("bias", _f),
                 ("N", C.c_int32), ("N_pad", C.c_int32), ("out", _f), ("out_stride", C.c_int32),
                 ("act", C.c_int32), ("precise", C.c_int32), ("out_scale", C.c_float),
-                ("out_split_bf16", _f), ("split_stride", C.c_int32), ("workspace", _f)]
+                ("out_split_bf16", _f), ("split_stride", C.c_int32), ("workspace", _f),
+                ("workspace_bytes", C.c_size_t)]
 
 
 CF_MAX_HEADS = 12

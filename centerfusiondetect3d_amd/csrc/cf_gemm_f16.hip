@@ -706,6 +706,8 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   // by the batch size: it changes the summation order, and a shard has to reproduce the full batch)
   const unsigned ks = a->workspace ? (unsigned)dcn_k_split(a->H, a->W, k.n_chunks, a->N_pad) : 1u;
   CF_REQUIRE(ks == 1 || !a->out_split_bf16, "cf_dcn_v2_f16x3: the split-bf16 output is not available on K-split maps");
+  CF_REQUIRE(ks == 1 || a->workspace_bytes >= (size_t)ks * M * a->N_pad * sizeof(float),
+             "cf_dcn_v2_f16x3: workspace of %zu bytes is smaller than cf_dcn_v2_workspace_bytes(...)", a->workspace_bytes);
   k.partial = static_cast<float*>(a->workspace);
   static const int direct_epi = [] { const char* e = getenv("CF_DCN_EPI"); return e ? atoi(e) == 0 : 0; }();
   k.direct_epilogue = direct_epi;

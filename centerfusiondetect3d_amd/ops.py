@@ -185,6 +185,7 @@ def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act
         a.out_split_bf16, a.split_stride = out_split.data_ptr(), out_split.shape[-1]
     if workspace is not None:            # K split on small maps (cf_dcn_v2_workspace_bytes)
         a.workspace = workspace.data_ptr()
+        a.workspace_bytes = workspace.numel() * workspace.element_size()
     return a
 
 

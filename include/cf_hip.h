@@ -210,6 +210,7 @@ typedef struct cf_dcn_args {
   void* workspace;      /* cf_dcn_v2_f16x3 only, optional: cf_dcn_v2_workspace_bytes(...) bytes.  With it, small
                            maps (<= 2048 pixels per image) split K over 2-4 workgroups per tile and a second
                            launch adds the partial sums in fixed order; without it K is never split */
+  size_t workspace_bytes; /* size of `workspace`; checked against cf_dcn_v2_workspace_bytes(...) when K is split */
 } cf_dcn_args;
 int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream);
 

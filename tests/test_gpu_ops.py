@@ -648,6 +648,21 @@ def test_dcn_v2_f16x3_rejects_odd_tile_counts_above_128(dev):
         ops.dcn_v2_fused(pd, torch.zeros(B, H, W, Ci, device=dev), torch.zeros(B, H, W, 32, device=dev))
 
 
+def test_dcn_v2_f16x3_checks_the_workspace_size(dev):
+    """K is split on small maps only into a workspace of at least cf_dcn_v2_workspace_bytes(...)."""
+    from centerfusiondetect3d_amd import ops, packing, _lib
+    B, Ci, Co, H, W = 1, 128, 64, 14, 25
+    pd = packing.pack_dcn_f16(rnd(Co, Ci, 3, 3, seed=3), rnd(Co, seed=4)).to(dev)
+    x, om = torch.zeros(B, H, W, Ci, device=dev), torch.zeros(B, H, W, 32, device=dev)
+    need = _lib.load().cf_dcn_v2_workspace_bytes(B, H, W, Ci, 64)
+    assert need > 0
+    out = torch.empty(B, H, W, Co, device=dev)
+    small = torch.empty(need - 4, device=dev, dtype=torch.uint8)
+    with pytest.raises(_lib.CfHipError):
+        ops.run_dcn(ops.dcn_args(pd, x, om, 32, B, H, W, out, Co, workspace=small))
+    ops.run_dcn(ops.dcn_args(pd, x, om, 32, B, H, W, out, Co, workspace=torch.empty(need, device=dev, dtype=torch.uint8)))
+
+
 # ----------------------------------------------------------------------------------- fused stem
 @pytest.mark.parametrize("B,C,H,W", [(2, 3, 64, 96), (1, 3, 16, 16), (1, 3, 34, 50), (3, 1, 18, 130), (1, 3, 160, 224)])
 def test_stem_fused(dev, B, C, H, W):
