@@ -245,6 +245,26 @@ def other_configs(dev, steps=12):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: run the ranks as children of torch.distributed.run (one process
+    per GPU, RCCL rendezvous on 127.0.0.1) - the reference gets its ranks from Lightning the same way
+    (/root/reference/src/lib/trainer.py:54-70, devices=config.GPUS).  Returns the children's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,26 +285,40 @@ def main():
     ap.add_argument("--exact-fp32", action="store_true",
                     help="every product in exact fp32 (fp32 MFMA kernels with two-level summation; conv_f16 / heads_bf16 "
                          "off) instead of the default split-operand products - the accuracy reference build, 3.5x slower")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the RCCL process group and issue the per-step all-gather also at world size 1 (what a "
+                         "rank of an N-GPU run does, on a one-GPU box)")
     ap.add_argument("--end-to-end", action="store_true",
                     help="print the Detector.run-shaped line instead (uint8 frames + raw radar over PCIe -> final boxes)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # started bare (`python bench.py --gpus N`): become the launcher.  This process has not touched the GPU (and
+        # never will - importing torch initialises nothing); the ranks are torch.distributed.run's children, rank 0
+        # prints the JSON line on the inherited stdout, and their exit code is ours.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+        print(f"bench.py[rank {rank}]: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree",
+              file=sys.stderr)
+        sys.exit(2)
+    n_dev = torch.cuda.device_count()          # (counting devices does not initialise HIP on this image)
+    if local_rank >= n_dev:
+        print(f"bench.py[rank {rank}]: needs GPU index {local_rank} but this node exposes {n_dev} device(s): "
+              f"--gpus {args.gpus} cannot run here", file=sys.stderr)
+        sys.exit(3)
     assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from centerfusiondetect3d_amd import getModel, centerfusion_middle_config, decode_post_packed
@@ -304,7 +338,7 @@ def main():
         return
     images, pc_dep, calib = make_inputs(B, H, W, dev, seed=1000 + rank)
     tinv = inverse_affine_device(np.array([800.0, 450.0], np.float32), 1600.0, (W // 4, H // 4), dev)
-    gatherer = DetectionGatherer(dev)
+    gatherer = DetectionGatherer(dev, force_collective=args.force_collective)
     pending = []
 
     def step():
@@ -398,7 +432,7 @@ def main():
         elif world == 1:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

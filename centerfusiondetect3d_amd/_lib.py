@@ -105,6 +105,7 @@ SYMBOLS = {
     "cf_decode_post": (_i, [C.POINTER(DecodeArgs), _f, _f, _f, _f]),
     "cf_serialize_nuscenes": (_i, [C.POINTER(SerializeArgs), _f]),
     "cf_serialize_max_candidates": (_i, []),
+    "cf_spin_us": (_i, [_i, _f]),
     "cf_last_error": (C.c_char_p, []),
     "cf_abi_version": (_i, []),
 }

@@ -95,6 +95,13 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
   }
 }
 
+// One workgroup that keeps its CU slot busy for `ticks` of the 100 MHz constant clock (s_memrealtime): the probe
+// host code uses to find out which HIP streams run concurrently (model.py: _side_streams).  Always terminates.
+__global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 inline int grid_for(long total) {
   long g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
@@ -147,4 +154,10 @@ extern "C" int cf_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, 
   dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, HW, C, c_stride);
   return cf_check_launch("cf_nhwc_to_nchw");
+}
+
+extern "C" int cf_spin_us(int microseconds, void* stream) {
+  CF_REQUIRE(microseconds > 0 && microseconds <= 100000, "cf_spin_us: %d us outside (0, 100000]", microseconds);
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
+  return cf_check_launch("cf_spin_us");
 }

@@ -151,20 +151,83 @@ def _param_spec(config) -> List[tuple]:
 
 
 # ----------------------------------------------------------------------------- execution plan
-_SIDE_STREAMS = {}    # (device, caller stream id) -> side streams, created once per PROCESS
-_SIDE_LOCK = __import__("threading").Lock()
+_SIDE_STREAMS = {}    # (device, caller stream id) -> probed side streams, LRU of _SIDE_KEYS keys per PROCESS
+_SIDE_KEYS = 16
+_SIDE_LOCK = threading.Lock()
+_PROBE_US = 300       # length of one probe spin; two of them take ~1x this when concurrent, ~2x when serialised
+_PROBE_LOG = []       # [(device, sid, n, chosen indices, [(i, j, ms)])]: what the probes measured (tests / DESIGN)
+
+
+def _concurrent(lib, a, b, us=_PROBE_US):
+    """True if a `cf_spin_us` on stream `a` and one on stream `b`, issued back to back, overlap in time.  HIP maps
+    streams onto a few hardware queues; two streams that share one run their kernels strictly one after the other
+    (model.streams = 2 then measures 10.5 instead of 8.5 ms per bs=16 step).  -> (bool, ms from first start to last end)"""
+    e0, e1a, e1b = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    gate = torch.cuda.Event()
+    gate.record(a)
+    b.wait_event(gate)                       # neither spin starts before both streams have drained to here
+    e0.record(a)
+    _lib.check(lib.cf_spin_us(us, a.cuda_stream), "cf_spin_us")
+    e1a.record(a)
+    _lib.check(lib.cf_spin_us(us, b.cuda_stream), "cf_spin_us")
+    e1b.record(b)
+    e1a.synchronize()
+    e1b.synchronize()
+    ms = max(e0.elapsed_time(e1a), e0.elapsed_time(e1b))
+    return ms < 1.6e-3 * us, ms
+
+
+def _pick_streams(device, cur, n, pool):
+    """Extend `pool` to n streams that run concurrently with each other (and, for the first one, with the caller's
+    stream `cur`: the two-lane neck issues on `cur` and on pool[0]).  Candidates are taken from torch's stream pool
+    one at a time and kept only if a pair of spin kernels says they overlap with everything chosen so far - whatever
+    else of the process (RCCL's communicator stream, other models, user streams) already sits on the hardware queues.
+    Falls back to plain creation order if no concurrent set turns up within 12 candidates (still correct, only slower)."""
+    lib = _lib.load()
+    torch.cuda.synchronize(device)
+    tried, log = [], []
+    while len(pool) < n and len(tried) < 12:
+        c = torch.cuda.Stream(device)
+        tried.append(c)
+        ok = True
+        for x in ([cur] if not pool else []) + pool:
+            good, ms = _concurrent(lib, x, c)
+            log.append((len(tried) - 1, "caller" if x is cur else pool.index(x), round(ms, 3)))
+            if not good:
+                ok = False
+                break
+        if ok:
+            pool.append(c)
+    fallback = len(pool) < n
+    for c in tried:                           # not enough concurrent ones: take what was created, in order
+        if len(pool) >= n:
+            break
+        if c not in pool:
+            pool.append(c)
+    _PROBE_LOG.append((str(device), int(cur.cuda_stream), n, fallback, log))
+    del _PROBE_LOG[:-32]
+    return pool
 
 
 def _side_streams(device, sid, n):
-    """The n side streams that work issued on caller stream `sid` of `device` forks onto.  One set per process, not per
-    model or plan: HIP spreads streams over a few hardware queues in creation order, and whether two side streams share
-    a queue decides whether their kernels overlap at all - measured 8.5 vs 10.5 ms per bs=16 step for the FIRST vs the
-    SECOND pair of streams created in a process (10.6 ms also with GPU_MAX_HW_QUEUES=2).  Every model therefore forks onto the pair
-    the first model got."""
+    """The n side streams that work issued on caller stream `sid` of `device` forks onto.  One set per process and caller
+    stream, not per model or plan, chosen ONCE by a probe (`_pick_streams`) instead of by creation order: HIP spreads
+    streams over a few hardware queues, whether two side streams share a queue decides whether their kernels overlap
+    at all (8.5 vs 10.5 ms per bs=16 step), and under torchrun RCCL has taken streams before the first model exists.
+    During a graph capture nothing may synchronise: fresh streams are forked as they come (the replay's placement is
+    the graph executor's, not these streams')."""
     with _SIDE_LOCK:
-        pool = _SIDE_STREAMS.setdefault((str(device), int(sid)), [])
-        while len(pool) < n:
-            pool.append(torch.cuda.Stream(device))
+        key = (str(device), int(sid))
+        pool = _SIDE_STREAMS.pop(key, [])
+        if len(pool) < n:
+            if torch.cuda.is_current_stream_capturing():
+                while len(pool) < n:
+                    pool.append(torch.cuda.Stream(device))
+            else:
+                pool = _pick_streams(device, torch.cuda.current_stream(device), n, pool)
+        _SIDE_STREAMS[key] = pool             # re-inserted last: dict order is the LRU order
+        while len(_SIDE_STREAMS) > _SIDE_KEYS:
+            _SIDE_STREAMS.pop(next(iter(_SIDE_STREAMS)))
         return pool[:n]
 
 
@@ -636,6 +699,8 @@ class DLASeg(nn.Module):
         self.heads_fused = True  # with heads_bf16: one launch per head group, hidden maps stay in LDS
         self.heads_mfma16 = True # fused heads: first layer + register-fed output layer on v_mfma_f32_16x16x32_bf16 (the
                                  # shape that holds the higher clock under load: 1.72 vs 1.51 PFLOP/s measured)
+        self.record_spans = False  # dev / tests: keep HIP events around each trunk of _forward_concurrent (trunk_overlap)
+        self.trunk_spans = []
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
         self.eval()
 
@@ -873,6 +938,7 @@ class DLASeg(nn.Module):
             feat = torch.empty((B, h4, w4, 64), device=dev, dtype=torch.float32)
             feat_in = torch.empty((B, h4, w4, 2, 64), device=dev, dtype=torch.bfloat16) if bf else feat
             hplan = self._plans[hkey] = _Plan(self, B, H, W, dev, part="heads", feat=feat, feat_in=feat_in)
+        spans = []
         for i in range(n):
             tkey = (B, k, H, W, dev, sid, "trunk", i)
             tplan = self._plans.get(tkey)
@@ -883,10 +949,27 @@ class DLASeg(nn.Module):
             s = pool[i]
             s.wait_stream(cur)
             with torch.cuda.stream(s):
+                if self.record_spans:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(s)
                 tplan.run_trunk(x[i * k:(i + 1) * k])
+                if self.record_spans:
+                    e1.record(s)
+                    spans.append((e0, e1))
         for s in pool:
             cur.wait_stream(s)
+        if self.record_spans:
+            self.trunk_spans = spans
         return hplan.run(self, None, pc_dep, calib)
+
+    def trunk_overlap(self):
+        """With `record_spans` set: the last concurrent forward's trunk spans -> (ms each trunk took, ms during which
+        the first two ran at the same time).  Streams on one hardware queue give ~0 overlap.  Syncs."""
+        torch.cuda.synchronize()
+        (a0, a1), (b0, b1) = self.trunk_spans[:2]
+        la, lb = a0.elapsed_time(a1), b0.elapsed_time(b1)
+        start_b = a0.elapsed_time(b0)                       # b's start relative to a's
+        return [la, lb], max(0.0, min(la, start_b + lb) - max(0.0, start_b))
 
 
     # ------------------------------------------------------------------------- instrumentation

@@ -362,6 +362,13 @@ int cf_serialize_max_candidates(void);
  * and the reference's own host side is Python.  The layouts the kernels expect are documented at each
  * argument block above and in DESIGN.md section 3. */
 
+/* cf_spin_us: diagnostic - ONE 64-thread workgroup that stays resident for `microseconds` (<= 100000) of the
+ * constant 100 MHz clock and then exits.  Two of them on two streams finish in ~1x the time when the streams run
+ * concurrently and in ~2x when HIP has put them on one hardware queue: the host's one-time stream-pair probe
+ * (centerfusiondetect3d_amd/model.py, _side_streams).  No reference counterpart (the reference leaves stream
+ * placement to PyTorch: it never forks streams). */
+int cf_spin_us(int microseconds, void* stream);
+
 const char* cf_last_error(void);
 int cf_abi_version(void);
 

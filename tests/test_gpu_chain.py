@@ -234,3 +234,59 @@ def test_rccl_all_gather_runs_on_device(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_trunk_streams_overlap_after_rccl_init(dev):
+    """What a rank of an N-GPU run does (bench.py under torchrun): the RCCL process group exists - and has taken its
+    streams - BEFORE the first model.  The two trunk sub-batches of `model.streams = 2` must still run concurrently
+    (the side-stream pair is chosen by a probe of spin kernels, model._pick_streams, not by creation order) and the
+    result must be the single-stream one bit for bit."""
+    import torch.distributed as dist
+    from centerfusiondetect3d_amd import getModel, centerfusion_middle_config
+    from centerfusiondetect3d_amd import model as M
+    from centerfusiondetect3d_amd.distributed import gather_detections
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        gather_detections(torch.randn(16, 100, 54, device=dev), force_collective=True)   # the communicator is live
+        M._SIDE_STREAMS.clear()                          # as in a fresh process: nothing probed yet
+        H, W, B = 448, 800, 16
+        m = getModel(centerfusion_middle_config((H, W)))
+        m.load_state_dict(cases.tuned_state_dict(radar=True, seed=0), strict=True)
+        m = m.to(dev).eval()
+        x, pc_dep, calib = cases.model_inputs(B, H, W, seed=47, radar=True, n_points=(50, 200))
+        xd, pd, cdv = x.to(dev), pc_dep.to(dev), calib.to(dev)
+        with torch.no_grad():
+            m.streams = 1
+            one = m(xd, pc_dep=pd, calib=cdv)[0]
+            m.streams, m.record_spans = 2, True
+            for _ in range(3):
+                two = m(xd, pc_dep=pd, calib=cdv)[0]
+            spans, overlap = m.trunk_overlap()
+        for k in one:
+            assert torch.equal(one[k], two[k]), k
+        probe = M._PROBE_LOG[-1]
+        print(f"trunk spans {spans[0]:.2f} / {spans[1]:.2f} ms, overlap {overlap:.2f} ms; probe {probe}")
+        assert not probe[3], f"no concurrent stream pair found: {probe}"
+        assert overlap >= 0.6 * min(spans), (spans, overlap, probe)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_stream_probe_tells_shared_queue_from_concurrent(dev):
+    """The probe's two answers, on this device: a stream against ITSELF is the serialised case (two spins take 2x),
+    and some pair among a handful of fresh streams is concurrent (1x)."""
+    from centerfusiondetect3d_amd import _lib
+    from centerfusiondetect3d_amd import model as M
+    lib = _lib.load()
+    s = [torch.cuda.Stream(dev) for _ in range(4)]
+    torch.cuda.synchronize()
+    same, ms_same = M._concurrent(lib, s[0], s[0])
+    assert not same and ms_same > 1.8e-3 * M._PROBE_US, ms_same
+    found = [(i, j) for i in range(4) for j in range(i + 1, 4) if M._concurrent(lib, s[i], s[j])[0]]
+    assert found, "no two of four fresh streams run concurrently"
+    assert lib.cf_spin_us(0, None) != 0 and lib.cf_spin_us(200000, None) != 0        # bounded by contract
