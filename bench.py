@@ -298,6 +298,12 @@ def main():
         # prints the JSON line on the inherited stdout, and their exit code is ours.
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
+    # stdout carries exactly ONE line, the JSON result: everything native code prints on fd 1 meanwhile (RCCL's version
+    # banner at communicator creation, for one) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -334,7 +340,7 @@ def main():
     model.streams = max(1, args.streams)
     if args.end_to_end:
         if rank == 0:
-            print(json.dumps(end_to_end(args, dev, model)), flush=True)
+            os.write(json_fd, (json.dumps(end_to_end(args, dev, model)) + "\n").encode())
         return
     images, pc_dep, calib = make_inputs(B, H, W, dev, seed=1000 + rank)
     tinv = inverse_affine_device(np.array([800.0, 450.0], np.float32), 1600.0, (W // 4, H // 4), dev)
@@ -431,7 +437,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(H, W, batch=B)
         elif world == 1:
             result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if collective:
         dist.destroy_process_group()
 
