@@ -6,6 +6,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcfhip.so")
 
+ABI_VERSION = 2      # CF_ABI_VERSION of include/cf_hip.h this binding was written against
 CF_MAX_SRC = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, ACT_RAW_AND_SIGDEPTH = 0, 1, 2, 3
 LAYOUT_NHWC, LAYOUT_NCHW, LAYOUT_NHWC_SPLIT_BF16 = 0, 1, 2
@@ -29,7 +30,7 @@ class DcnArgs(C.Structure):
                 ("N", C.c_int32), ("N_pad", C.c_int32), ("out", _f), ("out_stride", C.c_int32),
                 ("act", C.c_int32), ("precise", C.c_int32), ("out_scale", C.c_float),
                 ("out_split_bf16", _f), ("split_stride", C.c_int32), ("workspace", _f),
-                ("workspace_bytes", C.c_size_t)]
+                ("workspace_bytes", C.c_size_t), ("mask_activated", C.c_int32)]
 
 
 CF_MAX_HEADS = 12
@@ -92,6 +93,7 @@ SYMBOLS = {
     "cf_maxpool2x2": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "cf_nchw_to_nhwc4": (_i, [_f, _f, _i, _i, _i, _i, _f]),
     "cf_nhwc_to_nchw": (_i, [_f, _f, _i, _i, _i, _i, _i, _f]),
+    "cf_nchw_to_nhwc": (_i, [_f, _f, _i, _i, _i, _i, _i, _i, _f]),
     "cf_radar_ingest": (_i, [_f, _f, _i, _i, _i, _f, _i, _i, _d, _d, _i, _f, _f, _f, _f]),
     "cf_preprocess_images": (_i, [_f, _i, _i, _i, C.POINTER(C.c_double), C.POINTER(C.c_float),
                                  C.POINTER(C.c_float), _i, _i, _f, _f]),
@@ -129,6 +131,9 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.cf_abi_version() != ABI_VERSION:
+            raise CfHipError(f"{LIB_PATH} has ABI version {lib.cf_abi_version()}, this package needs {ABI_VERSION}: "
+                             "rebuild it with `python -m centerfusiondetect3d_amd.build`")
         _lib = lib
     return _lib
 

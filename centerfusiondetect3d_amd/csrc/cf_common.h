@@ -58,4 +58,13 @@ __device__ __forceinline__ int cf_xcd_remap(int b, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Lanes of ONE wave exchanging data through LDS (write as (row, channel), read back as (pixel, chunk)): orders this wave's
+// earlier LDS accesses before its later ones for the compiler (no reordering across it) and, through the wavefront-scope
+// release / acquire pair, in the memory model; the hardware executes one wave's DS operations in issue order anyway.
+__device__ __forceinline__ void cf_wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float cf_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

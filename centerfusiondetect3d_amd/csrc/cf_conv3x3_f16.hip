@@ -292,6 +292,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
       if (n + e < p.N) bias4[e] = p.bias[n + e];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
+      if (ct) cf_wave_lds_sync();            // ... and every lane has read the previous tile before it is overwritten
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -301,6 +302,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
           for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
           *reinterpret_cast<f32x4*>(eb + li * EROW + (rt * 32 + 8 * g + 4 * h) * 4) = v;
         }
+      cf_wave_lds_sync();                    // the tile is complete before any lane reads another lane's part ...
 #pragma unroll
       for (int it = 0; it < 32 / PPI; ++it) {
         const int ploc = it * PPI + psub;

@@ -95,6 +95,27 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
   }
 }
 
+// (B,C,H,W) -> (B,H,W,out_stride) at channel offset out_offset: the mirror image of nhwc_to_nchw_kernel (32 x 32 tiles
+// through LDS, both sides coalesced).  Module-boundary helper of the operator-level deform_conv2d drop-in.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           long HW, int C, int out_stride, int out_offset) {
+  __shared__ float tile[32][33];
+  const long p0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32, b = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const long p = p0 + tx;
+    tile[r][tx] = (p < HW && c < C) ? x[((long)b * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const long p = p0 + r;
+    const int c = c0 + tx;
+    if (p < HW && c < C) out[((long)b * HW + p) * out_stride + out_offset + c] = tile[tx][r];
+  }
+}
+
 // One workgroup that keeps its CU slot busy for `ticks` of the 100 MHz constant clock (s_memrealtime): the probe
 // host code uses to find out which HIP streams run concurrently (model.py: _side_streams).  Always terminates.
 __global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks) {
@@ -154,6 +175,18 @@ extern "C" int cf_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, 
   dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, HW, C, c_stride);
   return cf_check_launch("cf_nhwc_to_nchw");
+}
+
+extern "C" int cf_nchw_to_nhwc(const float* x, float* out, int B, int C, int H, int W, int out_stride, int out_offset,
+                               void* stream) {
+  CF_REQUIRE(x && out, "cf_nchw_to_nhwc: null buffer");
+  CF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && out_offset >= 0 && out_stride >= out_offset + C,
+             "cf_nchw_to_nhwc: bad geometry (C=%d, out_stride=%d, out_offset=%d)", C, out_stride, out_offset);
+  const long HW = (long)H * W;
+  CF_REQUIRE(B < 65536 && (C + 31) / 32 < 65536, "cf_nchw_to_nhwc: too many images / channels for the launch grid");
+  dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, HW, C, out_stride, out_offset);
+  return cf_check_launch("cf_nchw_to_nhwc");
 }
 
 extern "C" int cf_spin_us(int microseconds, void* stream) {

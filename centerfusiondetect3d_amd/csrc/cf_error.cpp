@@ -13,4 +13,4 @@ void cf_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cf_last_error(void) { return g_err; }
-extern "C" int cf_abi_version(void) { return 1; }
+extern "C" int cf_abi_version(void) { return CF_ABI_VERSION; }

@@ -43,6 +43,7 @@ struct DcnK {
   const float* om;
   const float* weight;
   int om_stride, H, W, C, K_pad, n_chunks, NT, chunks_per_tap;
+  int mask_activated;   // offmask channels 18..26 are modulation factors already (no sigmoid here)
   EpilogueArgs ep;
 };
 
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void dcn_igemm_kernel(DcnK p) {
       const int ti = tap / 3, tj = tap - ti * 3;
       d[0] = (float)(ho - 1 + ti) + om[2 * tap];
       d[1] = (float)(wo - 1 + tj) + om[2 * tap + 1];
-      d[2] = cf_sigmoid(om[18 + tap]);
+      d[2] = p.mask_activated ? om[18 + tap] : cf_sigmoid(om[18 + tap]);
     }
     desc[i] = d;
   }
@@ -558,6 +559,7 @@ extern "C" int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream) {
   k.K_pad = 9 * a->C;
   k.n_chunks = k.K_pad / CF_BK;
   k.chunks_per_tap = a->C / CF_BK;
+  k.mask_activated = a->mask_activated;
   k.ep = EpilogueArgs{a->bias, nullptr, a->out, nullptr, 0, a->out_stride, CF_LAYOUT_NHWC, a->act,
                       (int)M, a->N, a->H * a->W};
   const int N_pad = a->N_pad;

@@ -194,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvF p) {
       if (n + e < p.N) bias4[e] = p.bias[n + e];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
+      if (ct) cf_wave_lds_sync();            // ... and every lane has read the previous tile before it is overwritten
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvF p) {
           for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
           *reinterpret_cast<f32x4*>(eb + li * EROW + (rt * 32 + 8 * g + 4 * h) * 4) = v;
         }
+      cf_wave_lds_sync();                    // the tile is complete before any lane reads another lane's part ...
 #pragma unroll
       for (int it = 0; it < 32 / PPI; ++it) {
         const int ploc = it * PPI + psub;
@@ -248,6 +250,7 @@ struct DcnF {
   int split_stride;
   float* partial;        // K split (gridDim.z > 1): raw partial sums [z][M][n_rt * 32], reduced by dcn_reduce_kernel
   int direct_epilogue;   // dev A/B (CF_DCN_EPI=0): store the accumulators directly
+  int mask_activated;    // offmask channels 18..26 are modulation factors already (no sigmoid here)
 };
 
 template <int WC, int WP, int RT, bool COAL>
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
       dA[0] = __int_as_float(((b * p.H + y0) * p.W + x0) * p.C);
       dA[1] = __int_as_float((max(x1, x0) - x0) * p.C);
       dA[2] = __int_as_float((max(y1, y0) - y0) * p.W * p.C);
-      dA[3] = cf_sigmoid(omm[it]) * ASCALE;
+      dA[3] = (p.mask_activated ? omm[it] : cf_sigmoid(omm[it])) * ASCALE;
       dB[0] = (t_ok && l_ok) ? hh * hw : 0.0f;
       dB[1] = (t_ok && r_ok) ? hh * lw : 0.0f;
       dB[2] = (b_ok && l_ok) ? lh * hw : 0.0f;
@@ -505,6 +508,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     if (n_ok) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
+      if (ct) cf_wave_lds_sync();            // ... and every lane has read the previous tile before it is overwritten
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -514,6 +518,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
           for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
           *reinterpret_cast<f32x4*>(eb + li * EROW + (rt * 32 + 8 * g + 4 * h) * 4) = v;
         }
+      cf_wave_lds_sync();                    // the tile is complete before any lane reads another lane's part ...
 #pragma unroll
       for (int it = 0; it < 32 / PPI; ++it) {
         const int ploc = it * PPI + psub;
@@ -709,6 +714,7 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   CF_REQUIRE(ks == 1 || a->workspace_bytes >= (size_t)ks * M * a->N_pad * sizeof(float),
              "cf_dcn_v2_f16x3: workspace of %zu bytes is smaller than cf_dcn_v2_workspace_bytes(...)", a->workspace_bytes);
   k.partial = static_cast<float*>(a->workspace);
+  k.mask_activated = a->mask_activated;
   static const int direct_epi = [] { const char* e = getenv("CF_DCN_EPI"); return e ? atoi(e) == 0 : 0; }();
   k.direct_epilogue = direct_epi;
   const bool coal = (a->N & 3) == 0 && !k.direct_epilogue;   // whole-row epilogue through LDS

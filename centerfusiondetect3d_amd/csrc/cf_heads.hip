@@ -1167,7 +1167,7 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
     if (m16) {
       CF_REQUIRE(a->K_pad % 32 == 0 && a->K_pad / 32 >= (a->n_src == 2 ? 21 : 18), "cf_head_fused: K_pad=%d (16x16x32 fragments)", a->K_pad);
       for (int i = 0; i < a->tail.n_heads; ++i)
-        CF_REQUIRE(a->tail.n_hidden > 0 || a->tail.n_out[i] <= 16, "cf_head_fused: head %d: n_out=%d > 16 (16x16x32 output tile)", i, a->tail.n_out[i]);
+        CF_REQUIRE(a->tail.n_out[i] <= 16, "cf_head_fused: head %d: n_out=%d > 16 (the 16x16x32 kernels produce ONE 16-row output tile, with or without hidden layers)", i, a->tail.n_out[i]);
     }
     for (int i = 0; i < a->tail.n_heads; ++i) {
       CF_REQUIRE(a->tail.n_hidden > 0 || a->w_out_perm[i], "cf_head_fused: head %d: w_out_perm missing", i);
@@ -1245,6 +1245,9 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
       hipLaunchKernelGGL((head_patch_kernel<4, false>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
     return cf_check_launch("cf_head_fused");
   }
+  // the slot-table kernel reads every weight as 32x32x16 fragments: 16x16x32-packed ones would be misread silently
+  CF_REQUIRE(a->mfma16 == 0, "cf_head_fused: mfma16 fragments need the 3x3 patch layout (layout3x3 = 1, 64-channel first "
+                             "source [, 8-channel second]); this launch would run on the 32x32x16 slot-table kernel");
   static CfLdsLimit lds_limit;
   lds_limit.ensure(head_fused_kernel, HF_LDS, HF_LDS);
   const int tiles = (k.t.M + HT_PX - 1) / HT_PX;

@@ -815,7 +815,9 @@ class DLASeg(nn.Module):
                     pk[f"heads.{h}.{idx}"] = pack(hw(h, idx), hb(h, idx), [Source(256, ns, 256 * n)]).to(device)
                 pk[f"heads.{h}.out"] = pack(hw(h, 6), hb(h, 6), [Source(256, ns, 256 * n)]).to(device)
         if bf:
-            m16 = bool(self.heads_mfma16) and all(n <= 16 for n in heads.values())
+            # 16x16x32 fragments only where the kernel that reads them runs: the fused patch kernels (cf_head_tail and
+            # the slot-table head kernel read 32x32x16 fragments)
+            m16 = bool(self.heads_mfma16) and bool(self.heads_fused) and all(n <= 16 for n in heads.values())
             def tail(h, hidden_idx, out_idx):
                 n_out = heads[h]
                 b32 = torch.zeros(32)

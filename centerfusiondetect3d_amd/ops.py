@@ -160,7 +160,8 @@ def head_fused_args(srcs, src_strides, slots, k_pad, B, H, W, heads, layout3x3=N
         if hd.get("w_out_perm") is not None:
             f.w_out_perm[i] = hd["w_out_perm"].data_ptr()
     f.layout3x3 = int(all(hd.get("w_out_perm") is not None for hd in heads)) if layout3x3 is None else int(layout3x3)
-    f.mfma16 = int(all(bool(hd.get("mfma16")) for hd in heads))     # fragments packed for the 16x16x32 shape
+    f.mfma16 = int(all(bool(hd.get("mfma16")) for hd in heads))     # fragments packed for the 16x16x32 shape (the C
+    # side refuses them on a launch that does not take the 3x3 patch kernel: nothing else can read them)
     return f
 
 
@@ -206,6 +207,93 @@ def dcn_v2_fused(pd: PackedDcn, x, offmask, act=ACT_RELU, precise=True, k_split=
     a = dcn_args(pd, x, offmask, offmask.shape[-1], B, H, W, out, pd.n, act, precise, workspace=ws)
     run_dcn(a)
     return out
+
+
+def nchw_to_nhwc(x, out=None, out_offset=0):
+    """(B,C,H,W) fp32 -> (B,H,W,S) NHWC, written at channel `out_offset` of `out` (default: a fresh (B,H,W,C))."""
+    _need_cuda(x, out)
+    B, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().cf_nchw_to_nhwc(x.data_ptr(), out.data_ptr(), B, Cc, H, W, out.shape[-1], out_offset,
+                                           _lib.stream_ptr()), "cf_nchw_to_nhwc")
+    return out
+
+
+_DCN_PACKS = {}       # (weight ptr, version, bias ptr, version, shape, device) -> PackedDcn; LRU of _DCN_PACK_KEYS
+_DCN_PACK_KEYS = 64
+
+
+def _packed_dcn(weight, bias):
+    """Pack (split fp16 hi / lo, MFMA fragment order: packing.pack_dcn_f16) ONCE per weight tensor and version - the
+    reference calls the operator with the same nn.Parameter every forward (dla.py:464-465)."""
+    from . import packing
+    key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version),
+           tuple(weight.shape), str(weight.device))
+    pd = _DCN_PACKS.pop(key, None)
+    if pd is None:
+        w = weight.detach().float().cpu()
+        b = torch.zeros(w.shape[0]) if bias is None else bias.detach().float().cpu()
+        pd = packing.pack_dcn_f16(w, b).to(weight.device)
+    _DCN_PACKS[key] = pd                          # re-inserted last: dict order is the LRU order
+    while len(_DCN_PACKS) > _DCN_PACK_KEYS:
+        _DCN_PACKS.pop(next(iter(_DCN_PACKS)))
+    return pd
+
+
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else tuple(int(e) for e in v)
+
+
+def deform_conv2d(input, offset, weight, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), mask=None):
+    """Operator-level drop-in for `torchvision.ops.deform_conv2d` as the reference calls it
+    (model/networks/dla.py:461-470) - same signature, same semantics: `input` (B,Cin,H,W),
+    `offset` (B,18,H,W) with channel 2k = dy and 2k+1 = dx of tap k = 3i+j, `mask` (B,9,H,W) ALREADY activated (the
+    caller's sigmoid; None = unmodulated DCNv1), raw `weight` (Cout,Cin,3,3) and `bias` (Cout) -> (B,Cout,H,W), all
+    NCHW fp32 on the device.  `torchvision.ops.deform_conv2d = centerfusiondetect3d_amd.ops.deform_conv2d` lets the
+    reference's own `DeformConv` module run on the HIP kernel unchanged.
+
+    What runs: three layout launches (cf_nchw_to_nhwc: input, offset, mask -> the NHWC buffers the kernel reads),
+    cf_dcn_v2_f16x3 with `mask_activated`, cf_nhwc_to_nchw.  The module path (DLASeg) never takes this route: there
+    the maps stay NHWC and the mask logits go in raw.  Only the configuration the reference uses is implemented -
+    3x3, stride 1, padding 1, dilation 1, one group, one offset group, Cin a multiple of 32; anything else raises
+    NotImplementedError (no fallback)."""
+    _need_cuda(input, offset, weight, bias, mask)
+    if input.dim() != 4 or weight.dim() != 4:
+        raise ValueError("deform_conv2d: input must be (B,Cin,H,W) and weight (Cout,Cin,kh,kw)")
+    B, Cin, H, W = input.shape
+    Cout, Cw, kh, kw = weight.shape
+    if (kh, kw) != (3, 3) or _pair(stride) != (1, 1) or _pair(padding) != (1, 1) or _pair(dilation) != (1, 1):
+        raise NotImplementedError("deform_conv2d on the HIP path: 3x3, stride 1, padding 1, dilation 1 only "
+                                  "(the one configuration of dla.py:385-472)")
+    if Cw != Cin:
+        raise NotImplementedError("deform_conv2d on the HIP path: groups == 1 only")
+    if Cin % 32:
+        raise NotImplementedError(f"deform_conv2d on the HIP path: Cin={Cin} must be a multiple of 32")
+    if tuple(offset.shape) != (B, 18, H, W):
+        if offset.dim() == 4 and offset.shape[1] % 18 == 0 and offset.shape[1] > 18:
+            raise NotImplementedError("deform_conv2d on the HIP path: one offset group only")
+        raise ValueError(f"deform_conv2d: offset must be {(B, 18, H, W)}, got {tuple(offset.shape)}")
+    if mask is not None and tuple(mask.shape) != (B, 9, H, W):
+        raise ValueError(f"deform_conv2d: mask must be {(B, 9, H, W)}, got {tuple(mask.shape)}")
+    if bias is not None and tuple(bias.shape) != (Cout,):
+        raise ValueError(f"deform_conv2d: bias must be ({Cout},), got {tuple(bias.shape)}")
+    dev = input.device
+    pd = _packed_dcn(weight, bias)
+    x = nchw_to_nhwc(input.float().contiguous())
+    om = torch.empty((B, H, W, 32), device=dev, dtype=torch.float32)
+    nchw_to_nhwc(offset.float().contiguous(), om, 0)
+    if mask is None:
+        om[..., 18:27] = 1.0
+    else:
+        nchw_to_nhwc(mask.float().contiguous(), om, 18)
+    out = torch.empty((B, H, W, pd.n_pad), device=dev, dtype=torch.float32)     # (any Cout: the row stride is N_pad)
+    nbytes = _lib.load().cf_dcn_v2_workspace_bytes(B, H, W, pd.c, pd.n_pad)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8) if nbytes else None
+    a = dcn_args(pd, x, om, 32, B, H, W, out, pd.n_pad, ACT_NONE, precise=True, workspace=ws)
+    a.mask_activated = 1
+    run_dcn(a)
+    return nhwc_to_nchw(out, channels=pd.n)
 
 
 def upsample_dw(x, weight_kkc, f, skip=None, out=None):

@@ -23,6 +23,8 @@
 extern "C" {
 #endif
 
+#define CF_ABI_VERSION 2 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us */
+
 #define CF_OK 0
 #define CF_EINVAL (-22)
 #define CF_ELAUNCH (-5)
@@ -190,7 +192,7 @@ int cf_head_fused(const cf_head_fused_args* a, void* stream);
  * replaces torchvision.ops.deform_conv2d + BN + ReLU of model/networks/dla.py:456-472.
  * `offmask` is the raw output of conv_offset_mask, NHWC with `om_stride` floats per pixel:
  * channels 2k / 2k+1 = dy / dx of tap k, channels 18+k = mask logit of tap k (sigmoid applied
- * here) - the chunk/cat of dla.py:457-459 is the identity on the first 18 channels. */
+ * here unless mask_activated) - the chunk/cat of dla.py:457-459 is the identity on the first 18 channels. */
 typedef struct cf_dcn_args {
   const float* x;       /* NHWC [B][H][W][C]                    */
   const float* offmask; /* NHWC [B][H][W][om_stride], 27 used   */
@@ -211,6 +213,9 @@ typedef struct cf_dcn_args {
                            maps (<= 2048 pixels per image) split K over 2-4 workgroups per tile and a second
                            launch adds the partial sums in fixed order; without it K is never split */
   size_t workspace_bytes; /* size of `workspace`; checked against cf_dcn_v2_workspace_bytes(...) when K is split */
+  int32_t mask_activated; /* 0: offmask channels 18..26 are mask LOGITS, sigmoid applied here (the fused DeformConv of
+                             the module path); != 0: they already are the modulation factors, used as they are - the
+                             contract of torchvision.ops.deform_conv2d(mask=...) (dla.py:460: the caller's sigmoid) */
 } cf_dcn_args;
 int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream);
 
@@ -235,6 +240,12 @@ int cf_nchw_to_nhwc4(const float* x, float* out, int B, int C, int H, int W, voi
 
 /* cf_nhwc_to_nchw: generic layout change used to hand NHWC intermediates back in NCHW. */
 int cf_nhwc_to_nchw(const float* x, float* out, int B, int H, int W, int C, int c_stride,
+                    void* stream);
+
+/* cf_nchw_to_nhwc: (B,C,H,W) -> NHWC with `out_stride` floats per pixel, written at channel `out_offset`
+ * (the other channels of the destination are left alone).  Entry side of the operator-level deform_conv2d
+ * drop-in (ops.deform_conv2d: NCHW input / offset / mask of dla.py:461-470 -> the NHWC buffers of cf_dcn_v2_*). */
+int cf_nchw_to_nhwc(const float* x, float* out, int B, int C, int H, int W, int out_stride, int out_offset,
                     void* stream);
 
 /* cf_radar_ingest: raw radar sweeps -> what cf_pillar_expand consumes (detector.py:257-283,

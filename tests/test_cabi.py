@@ -27,7 +27,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in cf_hip.h but not exported by libcfhip.so"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes binding"
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.cf_abi_version() == 1
+    assert lib.cf_abi_version() == 2
     assert lib.cf_topk_workspace_bytes(16, 100) == 16 * 16 * 100 * 8
     assert lib.cf_topk_workspace_bytes_nms(16, 10, 112, 200, 100) == 16 * 16 * 100 * 8 + 16 * 10 * 112 * 200 * 4
 
@@ -98,3 +98,20 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libcfhip.so")
     with pytest.raises(_lib.CfHipError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_integration_md_shows_the_real_dcn_args():
+    """The ctypes struct INTEGRATION.md section 3b prints must be _lib.DcnArgs: same field names, types and size
+    (the round-2 document showed a struct five fields short)."""
+    import ctypes as C
+    import re
+    from centerfusiondetect3d_amd import _lib
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    m = re.search(r"^class DcnArgs\(C\.Structure\):.*?\n((?: {4}.*\n)+)", text, re.M)
+    assert m, "INTEGRATION.md no longer shows class DcnArgs"
+    ns = {"C": C}
+    exec(m.group(0), ns)
+    doc = ns["DcnArgs"]
+    assert [(n, t) for n, t in doc._fields_] == [(n, t) for n, t in _lib.DcnArgs._fields_]
+    assert C.sizeof(doc) == C.sizeof(_lib.DcnArgs)
+    assert f"CF_ABI_VERSION {_lib.ABI_VERSION}" in m.group(0)

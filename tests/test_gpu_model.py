@@ -501,3 +501,30 @@ def test_two_lane_neck_equals_single_stream(dev, radar, B, H, W):
         for k in one:
             if k != "calib":
                 assert torch.equal(y[k], one[k]), k
+
+
+@pytest.mark.parametrize("radar", [True, False])
+def test_unfused_head_path_matches_fused(dev, radar):
+    """model.heads_fused = False (first layers as cf_conv2d_bf16x3, tails as cf_head_tail - 32x32x16 fragments) with
+    the default heads_mfma16 = True: round 2 packed 16x16x32 fragments for kernels that read 32x32x16 ones and the
+    outputs were silently wrong.  Both paths against the oracle, and against each other within bf16x3
+    rounding."""
+    H, W, B = 128, 160, 2
+    sd = cases.tuned_state_dict(radar=radar, seed=0)
+    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=3, radar=radar)
+    kw = dict(pc_dep=pc_dep.to(dev), calib=calib.to(dev)) if radar else {}
+    with torch.no_grad():
+        ref = model_ref.forward(sd, x, pc_dep=pc_dep if radar else None, calib=calib, radar=radar)[0]
+        outs = {}
+        for fused in (True, False):
+            m = _model(radar, dev, (H, W))
+            assert m.heads_mfma16
+            m.heads_fused = fused
+            outs[fused] = m(x.to(dev), **kw)[0]
+            names = {s[0].__name__ for p in m._plans.values() for s in p.steps if s and not isinstance(s[0], str)}
+            assert ("cf_head_tail" in names) == (not fused) and ("cf_head_fused" in names) == fused
+    for k, v in ref.items():
+        if k == "calib":
+            continue
+        for fused in (True, False):
+            _assert_maps_close(outs[fused][k].cpu(), v, f"{k}[fused={fused}]")

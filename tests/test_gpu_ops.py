@@ -490,6 +490,39 @@ def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W, patch):
             close(hd["out2"], 1.0 / (torch.sigmoid(raw) + 1e-6) - 1.0, 1e-3, 1e-3)
 
 
+def test_head_fused_refuses_mfma16_fragments_it_cannot_read(dev):
+    """16x16x32-packed weights are only readable by the 3x3 patch kernels: (a) a launch that would fall to the
+    slot-table kernel (no w_out_perm -> layout3x3 = 0) with mfma16 set, and (b) a 16x16x32 head with more than 16
+    outputs - with or without hidden layers - are refused, not run."""
+    from centerfusiondetect3d_amd import ops, packing, _lib
+    B, H, W = 1, 8, 16
+    feat = rnd(B, 64, H, W, seed=1)
+    srcs = [_split(feat, dev)]
+    w1, b1 = rnd(256, 64, 3, 3, seed=2, scale=1 / 24), rnd(256, seed=3)
+    pc = packing.pack_conv_bf16(w1, b1, [packing.Source(64, 64)], fragments=16).to(dev)
+
+    def head(n_out, n_hidden, perm=True):
+        w = rnd(n_out, 256, 1, 1, seed=4, scale=1 / 16)
+        wp = torch.zeros(max(n_out, 16), 256)
+        wp[:n_out] = w.view(n_out, 256)
+        wh = [packing.pack_fragments16(rnd(256, 256, seed=5 + l, scale=1 / 16)).to(dev) for l in range(n_hidden)]
+        return dict(w_first=pc.weight, b_first=pc.bias[:256].contiguous(), w_hidden=wh,
+                    b_hidden=[torch.zeros(256, device=dev)] * n_hidden, w_out=packing.pack_fragments16(wp[:16]).to(dev),
+                    b_out=torch.zeros(32, device=dev), w_out_perm=packing.pack_fragments16(wp[:16], acc_order=True).to(dev) if perm else None,
+                    mfma16=True, n_out=n_out, act=0, out=torch.empty(B, n_out, H, W, device=dev), out2=None)
+
+    ok = ops.head_fused_args(srcs, [64], pc.slots, pc.k_pad, B, H, W, [head(8, 0)])
+    ops.run_head_fused(ok)                                           # the accepted form runs
+    f = ops.head_fused_args(srcs, [64], pc.slots, pc.k_pad, B, H, W, [head(8, 0, perm=False)])
+    assert f.layout3x3 == 0 and f.mfma16 == 1
+    with pytest.raises(_lib.CfHipError, match="mfma16"):
+        ops.run_head_fused(f)
+    for n_hidden in (0, 2):
+        f = ops.head_fused_args(srcs, [64], pc.slots, pc.k_pad, B, H, W, [head(24, n_hidden)])
+        with pytest.raises(_lib.CfHipError, match="n_out=24"):
+            ops.run_head_fused(f)
+
+
 # ----------------------------------------------------------------------------------- postProcess
 @pytest.mark.parametrize("seed", [0, 1])
 def test_post_process_vs_reference_golden(dev, golden_dir, seed):

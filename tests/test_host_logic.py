@@ -213,3 +213,21 @@ def test_no_exec_masked_prefetch_in_pinned_loops():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_isa.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "conv3x3_f16x3_kernel" in r.stdout and "head_patch16_kernel" in r.stdout
+
+
+def test_deform_conv2d_has_torchvisions_signature():
+    """The operator-level drop-in binds exactly as torchvision.ops.deform_conv2d does (names, order, defaults), so the
+    reference's keyword call (model/networks/dla.py:461-470) and positional calls both land; without a GPU it raises
+    CfHipError - there is no CPU path behind it."""
+    import inspect
+    import pytest
+    import torch
+    from centerfusiondetect3d_amd import ops, _lib
+    sig = inspect.signature(ops.deform_conv2d)
+    assert [(p.name, p.default) for p in sig.parameters.values()] == [
+        ("input", inspect.Parameter.empty), ("offset", inspect.Parameter.empty), ("weight", inspect.Parameter.empty),
+        ("bias", None), ("stride", (1, 1)), ("padding", (0, 0)), ("dilation", (1, 1)), ("mask", None)]
+    x, off, w = torch.zeros(1, 32, 4, 4), torch.zeros(1, 18, 4, 4), torch.zeros(8, 32, 3, 3)
+    with pytest.raises(_lib.CfHipError):
+        ops.deform_conv2d(input=x, offset=off, weight=w, bias=None, stride=(1, 1), padding=(1, 1), dilation=(1, 1),
+                          mask=torch.ones(1, 9, 4, 4))
