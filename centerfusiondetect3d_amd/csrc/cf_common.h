@@ -62,9 +62,11 @@ __device__ __forceinline__ int cf_xcd_remap(int b, int nblk) {
 // earlier LDS accesses before its later ones for the compiler (no reordering across it) and, through the wavefront-scope
 // release / acquire pair, in the memory model; the hardware executes one wave's DS operations in issue order anyway.
 __device__ __forceinline__ void cf_wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifndef CF_NO_WAVE_SYNC   // (dev A/B only: -DCF_NO_WAVE_SYNC measures what the ordering costs - nothing)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (workgroup scope: emits s_waitcnt lgkmcnt(0))
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 __device__ __forceinline__ float cf_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -2,7 +2,13 @@
 (`__builtin_amdgcn_sched_barrier` regions) of the MFMA kernels there must be NO exec-masked vector-memory load -
 every lane always loads from a valid (clamped) address and out-of-range contributions are removed by a select or a
 zero weight.  (Operand-class loads = dwordx2/x4; the scalar-width bias reads of the store epilogues are consumed at once.)  Compiles the sources to gfx950 assembly (no GPU needed) and scans them.
-    python tools/check_isa.py            -> exit status 0 if the invariant holds"""
+Two more invariants on the same listings:
+  * coalesced epilogues (conv_f16x3 / dcn_f16x3 / conv3x3_f16x3): the lanes of a wave exchange their output tile through
+    LDS; between the tile's ds_write group and the first ds_read behind it there must be an `s_waitcnt lgkmcnt(0)`
+    (cf_wave_lds_sync, ADVICE r2) - checked behind the last v_mfma of every such kernel;
+  * no `scratch_` instruction between the first and the last v_mfma of a HOT kernel (spills inside the
+    MFMA loop); `--scratch-report` only lists them, the default fails on them for the kernels in NO_SCRATCH.
+    python tools/check_isa.py            -> exit status 0 if the invariants hold"""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,9 +48,66 @@ def violations(lines):
     return bad
 
 
+EPILOGUE_KERNELS = ("conv_f16x3_kernel", "dcn_f16x3_kernel", "conv3x3_f16x3_kernel")
+# kernels whose MFMA loop must be free of scratch traffic (every instantiation the default path launches)
+NO_SCRATCH = ()       # filled in as the instantiations are cleaned up
+
+
+def epilogue_violations(lines):
+    """ds_read behind a ds_write of the same wave with no `s_waitcnt lgkmcnt(0)` in between, in the epilogue = behind the
+    main loop's last barrier (the tile exchange uses LDS that is free from there on)."""
+    mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+    if not mf:
+        return []
+    start = mf[-1]
+    for i in range(mf[-1], len(lines)):
+        if re.search(r"\bs_barrier\b", lines[i].split(";")[0]):
+            start = i
+    bad, pending = [], False
+    for i in range(start, len(lines)):
+        l = lines[i].split(";")[0]
+        if re.search(r"\bds_write", l):
+            pending = True
+        elif re.search(r"s_waitcnt.*lgkmcnt\(0\)", l) or re.search(r"\bs_barrier\b", l):
+            pending = False
+        elif pending and re.search(r"\bds_read", l):
+            bad.append((i, l.strip()))
+            pending = False
+    return bad
+
+
+def scratch_in_mfma_loop(lines):
+    """scratch_load / scratch_store inside an MFMA stream: in ONE basic block (no label, no branch in between) with a
+    v_mfma before it and a v_mfma after it.  Spills at the boundaries of an outer loop (between blocks) do not count."""
+    def edge(l):
+        c = l.split(";")[0].strip()
+        return bool(re.match(r"^\.?L?\w+:", c)) or bool(re.match(r"s_(c)?branch", c)) or c.startswith("s_endpgm")
+    bad = []
+    for i, l in enumerate(lines):
+        if not re.match(r"\s*scratch_", l):
+            continue
+        before = after = False
+        for j in range(i - 1, -1, -1):
+            if edge(lines[j]):
+                break
+            if "v_mfma" in lines[j]:
+                before = True
+                break
+        for j in range(i + 1, len(lines)):
+            if edge(lines[j]):
+                break
+            if "v_mfma" in lines[j]:
+                after = True
+                break
+        if before and after:
+            bad.append((i, l.strip()))
+    return bad
+
+
 def main():
     hipcc = "/opt/rocm/bin/hipcc"
     failed = False
+    report_only = "--scratch-report" in sys.argv
     with tempfile.TemporaryDirectory() as tmp:
         for src, kernels in SOURCES.items():
             out = os.path.join(tmp, src + ".s")
@@ -54,6 +117,15 @@ def main():
             for name, lines in functions(open(out).read()).items():
                 if not any(k in name for k in kernels):
                     continue
+                if any(k in name for k in EPILOGUE_KERNELS):
+                    ev = epilogue_violations(lines)
+                    if ev:
+                        print(f"{src}: {name[:90]}: {len(ev)} epilogue ds_read not ordered behind its ds_write group")
+                        failed = True
+                sc = scratch_in_mfma_loop(lines)
+                if sc:
+                    print(f"{src}: {name[:90]}: {len(sc)} scratch ops inside an MFMA stream (same basic block, MFMAs on both sides)")
+                    failed |= (not report_only) and any(k in name for k in NO_SCRATCH)
                 v = violations(lines)
                 if v is None:
                     print(f"{src}: {name[:80]}: no pinned region")
