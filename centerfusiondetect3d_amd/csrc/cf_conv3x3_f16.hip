@@ -282,6 +282,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     constexpr int EROW = RT * 128 + 16;      // bytes per pixel row of the tile: +16 B so that 16 lanes hit 64 banks
     constexpr int LPP = RT * 8;              // lanes (16-byte chunks) per pixel
     constexpr int PPI = 64 / LPP;            // pixels per instruction
+    asm volatile("; cf_epilogue_begin" ::: "memory");   // marker for tools/check_isa.py (no instruction)
     unsigned char* eb = smem + wave * 32 * EROW;
     const int chunk = lane % LPP, psub = lane / LPP;
     const int n = rt0 * 32 + chunk * 4;

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvF p) {
   // private LDS tile (free after the loop's last barrier) and stores / reads the residual as whole pixel rows
   if (w_ok) {
     constexpr int LPP = RT * 8, PPI = 64 / LPP;
+    asm volatile("; cf_epilogue_begin" ::: "memory");   // marker for tools/check_isa.py (no instruction)
     unsigned char* eb = smem + wave * 32 * EROW;
     const int chunk = lane % LPP, psub = lane / LPP;
     const int n = rt0 * 32 + chunk * 4;
@@ -500,6 +501,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   if (coalesced && w_ok) {
     constexpr int EROW = RT * 128 + 16;
     constexpr int LPP = RT * 8, PPI = 64 / LPP;
+    asm volatile("; cf_epilogue_begin" ::: "memory");   // marker for tools/check_isa.py (no instruction)
     unsigned char* eb = smem + wave * 32 * EROW;
     const int chunk = lane % LPP, psub = lane / LPP;
     const int n = rt0 * 32 + chunk * 4;

@@ -14,7 +14,7 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "centerfusiondetect3d_amd", "csrc")
 SOURCES = {"cf_conv3x3_f16.hip": ("conv3x3_f16x3_kernel",), "cf_heads.hip": ("head_patch_kernel", "head_patch16_kernel"),
-           "cf_gemm_f16.hip": ("dcn_f16x3_kernel",)}
+           "cf_gemm_f16.hip": ("dcn_f16x3_kernel", "conv_f16x3_kernel")}
 
 
 def functions(asm):
@@ -55,14 +55,11 @@ NO_SCRATCH = ()       # filled in as the instantiations are cleaned up (DESIGN.m
 
 def epilogue_violations(lines):
     """ds_read behind a ds_write of the same wave with no `s_waitcnt lgkmcnt(0)` in between, in the epilogue = behind the
-    main loop's last barrier (the tile exchange uses LDS that is free from there on)."""
-    mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
-    if not mf:
-        return []
-    start = mf[-1]
-    for i in range(mf[-1], len(lines)):
-        if re.search(r"\bs_barrier\b", lines[i].split(";")[0]):
-            start = i
+    `; cf_epilogue_begin` marker the kernels emit (asm volatile comment) where the tile exchange starts."""
+    marks = [i for i, l in enumerate(lines) if "cf_epilogue_begin" in l]
+    if not marks:
+        return None                            # this instantiation stores its accumulators directly (no exchange)
+    start = marks[0]
     bad, pending = [], False
     for i in range(start, len(lines)):
         l = lines[i].split(";")[0]
@@ -108,6 +105,7 @@ def main():
     hipcc = "/opt/rocm/bin/hipcc"
     failed = False
     report_only = "--scratch-report" in sys.argv
+    seen_epilogues = set()
     with tempfile.TemporaryDirectory() as tmp:
         for src, kernels in SOURCES.items():
             out = os.path.join(tmp, src + ".s")
@@ -119,6 +117,8 @@ def main():
                     continue
                 if any(k in name for k in EPILOGUE_KERNELS):
                     ev = epilogue_violations(lines)
+                    if ev is not None:
+                        seen_epilogues.add(next(k for k in EPILOGUE_KERNELS if k in name))
                     if ev:
                         print(f"{src}: {name[:90]}: {len(ev)} epilogue ds_read not ordered behind its ds_write group")
                         failed = True
@@ -134,6 +134,10 @@ def main():
                 for i, l in v[:5]:
                     print(f"      line {i}: {l}")
                 failed |= bool(v)
+    missing = set(EPILOGUE_KERNELS) - seen_epilogues
+    if missing:
+        print(f"no instantiation of {sorted(missing)} carries the cf_epilogue_begin marker")
+        failed = True
     return 1 if failed else 0
 
 
