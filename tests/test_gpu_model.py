@@ -101,7 +101,7 @@ def test_accuracy_anchored_on_float64(dev, radar, B, H, W):
     with torch.no_grad():
         y = m(x.to(dev), pc_dep=pc_dep.to(dev) if radar else None, calib=calib.to(dev))[0]
     if not radar:
-        assert len(m.heads) == 9 and set(y) == set(r64)          # CenterNet.yaml: 9 heads, one hidden layer each, no radar
+        assert len(m.heads) == 9 and set(r64) <= set(y)           # CenterNet.yaml: 9 heads, one hidden layer each, no radar
     if radar:
         # discrete path first: same painted map as the fp32 oracle, bit for bit
         assert torch.equal(y["pc_hm"].cpu(), r32["pc_hm"]) and int((r32["pc_hm"] != 0).sum()) > 0
