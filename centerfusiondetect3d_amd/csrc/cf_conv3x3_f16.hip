@@ -40,17 +40,22 @@ struct Conv3F {
 // plus a one-pixel frame, (R/16 + 2) x 18 rows, zero-filled outside the image - so no tap needs a
 // validity select and the tap offsets are compile-time constants.  Pays on wide maps (W = 200: 1.3x
 // input traffic instead of 2.6x) whenever W is close to a multiple of 16.
-template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2>
+// CT = 32-pixel column tiles per wave: 2 (64 x 64 wave tiles, two waves per SIMD at 256 registers each) or 4 - the
+// ONE-WAVE-PER-SIMD form (MINB = 1, 512 registers: both accumulator sets of a 64-channel x 128-pixel tile, 256 registers,
+// sit in AGPRs; every weight fragment is fetched once per 128 pixels instead of once per 64).
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2, int CT = 2>
 __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
   constexpr int NT = 64 * WC * WP * WK;     // 4 waves, or 8 (WP doubled: two pixel groups share each weight fragment through L1)
   static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
-  constexpr int R = 64 * WP;
+  constexpr int R = 32 * CT * WP;
   constexpr int PW2 = 18;                   // T2: patch width (16 + 2)
   constexpr int ROWB = 64 * WK + 16;        // per patch row: WK x (16 hi + 16 lo f16) + pad (odd multiple of 16 B)
   constexpr int UPR = 4 * WK;               // 16-byte fp32 units per patch row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the wave index is wave-uniform: read through readfirstlane so that everything derived from it (the wave's channel
+  // group, its weight tile addresses, its k-steps) is scalar - SGPRs and scalar ALU instead of per-lane registers
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, h = lane >> 5;
   const int wk = wave % WK, wp = (wave / WK) % WP, wc = wave / (WK * WP);
 #ifdef CF_CONV3_PROF   // dev (tools/prof_conv3.py): cycles per phase of thread 0, written over its first output values
@@ -113,10 +118,12 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     }
   };
   auto store_patch = [&](unsigned char* buf, int lo, int hi) {
+    int tid_s = threadIdx.x;                 // (laundered: the NU destination addresses are re-derived per call - 3 ALU
+    asm volatile("" : "+v"(tid_s));          //  instructions each - instead of living in registers / scratch all loop long)
 #pragma unroll
     for (int it = 0; it < NU; ++it) {
       if (it < lo || it >= hi) continue;
-      const int u = tid + NT * it;
+      const int u = tid_s + NT * it;
       const int row = u / UPR, q = u % UPR;
       if (row < p.PR) {
         const f32x4 xs = goff[it] >= 0 ? raw[it] * ASCALE : f32x4{0.f, 0.f, 0.f, 0.f};   // (a select: the dummy read may hold anything)
@@ -131,11 +138,11 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
   };
 
   // ---- MFMA role: per column tile the patch row of this lane's pixel and its 9-bit tap validity
-  int rowb[2];
-  unsigned vmask[2];
+  int rowb[CT];
+  unsigned vmask[CT];
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int pl = wp * 64 + ct * 32 + li;
+  for (int ct = 0; ct < CT; ++ct) {
+    const int pl = wp * (32 * CT) + ct * 32 + li;
     const int m = m0 + pl;
     rowb[ct] = (T2 ? (pl >> 4) * PW2 + (pl & 15) : pl) * ROWB + wk * 64 + h * 16;
     unsigned mk = 0;
@@ -153,11 +160,11 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     vmask[ct] = mk;
   }
 
-  f32x16 accm[RT][2], accs[RT][2];
+  f32x16 accm[RT][CT], accs[RT][CT];
 #pragma unroll
   for (int a = 0; a < RT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < CT; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         accm[a][b][r] = 0.0f;
@@ -167,12 +174,16 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
   // weight fragments three taps ahead: set (t % 3) holds tap t
   f16x8 wh[3][RT], wl[3][RT];
   const int ks_last = (p.n_rounds * WK - WK + wk) * 9 + 8;      // this wave's last k-step
+  // fragment address = scalar tile base (row tile, k-step: uniform) + 16 * lane + 1 KiB for the lo plane: one per-lane
+  // 32-bit offset register serves every weight load of the kernel
+  const unsigned lane16 = (unsigned)lane * 16u;
   auto load_w = [&](f16x8 (&dh)[RT], f16x8 (&dl)[RT], int ks) {
     ks = min(ks, ks_last);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      dh[rt] = *wfrag16(p.weight, w_ok ? rt0 + rt : 0, ks, 0, p.n_ks, lane);
-      dl[rt] = *wfrag16(p.weight, w_ok ? rt0 + rt : 0, ks, 1, p.n_ks, lane);
+      const unsigned char* base = p.weight + ((size_t)(w_ok ? rt0 + rt : 0) * p.n_ks + ks) * 2048;
+      dh[rt] = *reinterpret_cast<const f16x8*>(base + lane16);
+      dl[rt] = *reinterpret_cast<const f16x8*>(base + 1024 + lane16);
     }
   };
 
@@ -192,36 +203,36 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     // B fragments: the hi plane one tap ahead (xh[t & 1]), the lo plane - needed only by the third
     // sweep - at the start of its tap; weights three taps ahead.  The sched_barrier after every tap
     // keeps the compiler from sinking those prefetches back down to their first use
-    f16x8 xh[2][2], xl[2];
+    f16x8 xh[2][CT], xl[CT];
     auto x_addr = [&](int ct, int t, int toff) { return (T2 || ((vmask[ct] >> t) & 1u)) ? rowb[ct] + toff : zrow; };
     int toff = 0;                            // ((t / 3) * W + t % 3) * ROWB, built incrementally
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) xh[0][ct] = *reinterpret_cast<const f16x8*>(cur + x_addr(ct, 0, 0));
+    for (int ct = 0; ct < CT; ++ct) xh[0][ct] = *reinterpret_cast<const f16x8*>(cur + x_addr(ct, 0, 0));
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) xl[ct] = *reinterpret_cast<const f16x8*>(cur + x_addr(ct, t, toff) + 32);
+      for (int ct = 0; ct < CT; ++ct) xl[ct] = *reinterpret_cast<const f16x8*>(cur + x_addr(ct, t, toff) + 32);
       toff += (t % 3 == 2) ? ((T2 ? PW2 : p.W) - 2) * ROWB : ROWB;
       if (t + 1 < 9) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
           xh[(t + 1) & 1][ct] = *reinterpret_cast<const f16x8*>(cur + x_addr(ct, t + 1, toff));
       }
       // three independent sweeps over the tiles: no MFMA waits on the one issued just before it
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
           accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t % 3][rt], xh[t & 1][ct], accs[rt][ct], 0, 0, 0);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
           accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t % 3][rt], xh[t & 1][ct], accm[rt][ct], 0, 0, 0);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
           accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t % 3][rt], xl[ct], accs[rt][ct], 0, 0, 0);
       // tap t+3 of this round, or tap t-6 of the next one (same set either way)
       load_w(wh[t % 3], wl[t % 3], t + 3 < 9 ? ks0 + t + 3 : ks0 + 9 * WK + t - 6);
@@ -251,22 +262,22 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            red[(((wave * RT + rt) * 2 + ct) * 16 + r) * 64 + lane] = accm[rt][ct][r] + accs[rt][ct][r];
+            red[(((wave * RT + rt) * CT + ct) * 16 + r) * 64 + lane] = accm[rt][ct][r] + accs[rt][ct][r];
     }
     __syncthreads();
     if (wk > 0) return;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float s = accm[rt][ct][r] + accs[rt][ct][r];
 #pragma unroll
-          for (int k = 1; k < WK; ++k) s += red[((((wave + k) * RT + rt) * 2 + ct) * 16 + r) * 64 + lane];
+          for (int k = 1; k < WK; ++k) s += red[((((wave + k) * RT + rt) * CT + ct) * 16 + r) * 64 + lane];
           accm[rt][ct][r] = s;
           accs[rt][ct][r] = 0.0f;
         }
@@ -283,6 +294,13 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     constexpr int LPP = RT * 8;              // lanes (16-byte chunks) per pixel
     constexpr int PPI = 64 / LPP;            // pixels per instruction
     asm volatile("; cf_epilogue_begin" ::: "memory");   // marker for tools/check_isa.py (no instruction)
+    // every lane-derived index of the epilogue is RE-derived here from a laundered thread id: computed once at the top of
+    // the kernel they would stay live (or be spilled to scratch) across the whole MFMA loop that never uses them
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane = tid_e & 63, wave = __builtin_amdgcn_readfirstlane(tid_e >> 6), li = lane & 31, h = lane >> 5;
+    const int wp = (wave / WK) % WP, wc = wave / (WK * WP);
+    const int rt0 = (blockIdx.y * WC + wc) * RT;
     unsigned char* eb = smem + wave * 32 * EROW;
     const int chunk = lane % LPP, psub = lane / LPP;
     const int n = rt0 * 32 + chunk * 4;
@@ -292,7 +310,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     for (int e = 0; e < 4; ++e)
       if (n + e < p.N) bias4[e] = p.bias[n + e];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
       if (ct) cf_wave_lds_sync();            // ... and every lane has read the previous tile before it is overwritten
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
 #pragma unroll
       for (int it = 0; it < 32 / PPI; ++it) {
         const int ploc = it * PPI + psub;
-        const int pl = wp * 64 + ct * 32 + ploc;
+        const int pl = wp * (32 * CT) + ct * 32 + ploc;
         int m = m0 + pl;
         bool ok = n_ok;
         if (T2) {
@@ -339,9 +357,9 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
 
   // ---- epilogue, direct form (K-split waves, N not a multiple of 4): lane = pixel, register group g = 4 consecutive channels
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
+  for (int ct = 0; ct < CT; ++ct) {
     if (coalesced) break;
-    const int pl = wp * 64 + ct * 32 + li;
+    const int pl = wp * (32 * CT) + ct * 32 + li;
     int m = m0 + pl;
     if (T2) {
       const int y = ty0 + (pl >> 4), x = tx0 + (pl & 15);
@@ -388,9 +406,9 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
 #endif
 }
 
-template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2 = false>
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2 = false, int CT = 2>
 bool try_launch(Conv3F k, int batch, hipStream_t st) {
-  constexpr int R = 64 * WP, ROWB = 64 * WK + 16;
+  constexpr int R = 32 * CT * WP, ROWB = 64 * WK + 16;
   long blocks;
   if (T2) {
     k.PR = (R / 16 + 2) * 18;
@@ -405,11 +423,11 @@ bool try_launch(Conv3F k, int batch, hipStream_t st) {
   constexpr int NT = 64 * WC * WP * WK;
   if (units > (long)NT * NU || blocks >= (1L << 31)) return false;
   size_t dyn = (size_t)(DB ? 2 : 1) * (k.PR + 1) * ROWB;
-  if (WK > 1) dyn = dyn < (size_t)4 * RT * 2 * 16 * 64 * 4 ? (size_t)4 * RT * 2 * 16 * 64 * 4 : dyn;
+  if (WK > 1) dyn = dyn < (size_t)4 * RT * CT * 16 * 64 * 4 ? (size_t)4 * RT * CT * 16 * 64 * 4 : dyn;
   constexpr size_t epi = (size_t)(64 * WC * WP * WK / 64) * 32 * (RT * 128 + 16);   // the waves' transposition tiles
   if (WK == 1 && NT == 256 && dyn < epi) dyn = epi;
   if (dyn > 160 * 1024) return false;
-  auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB, T2>;
+  auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB, T2, CT>;
   static CfLdsLimit lds_limit;                // (one per template instantiation)
   lds_limit.ensure(kernel, dyn, 65536);
   const dim3 grid((unsigned)blocks, (unsigned)((k.n_rt + WC * RT - 1) / (WC * RT)));
@@ -464,16 +482,21 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
   };
   // dev override (tools/bench_conv_cfg.py): CF_CONV3_CFG="WC,WP,WK[,T2]" forces one of the instantiated tilings
   if (const char* force = getenv("CF_CONV3_CFG")) {
-    int wc = 0, wp = 0, wk = 0, t2f = 0;
-    if (sscanf(force, "%d,%d,%d,%d", &wc, &wp, &wk, &t2f) >= 3 && cfg(wk)) {
+    int wc = 0, wp = 0, wk = 0, t2f = 0, ct = 2;
+    if (sscanf(force, "%d,%d,%d,%d,%d", &wc, &wp, &wk, &t2f, &ct) >= 3 && cfg(wk)) {
       const int key = wc * 100 + wp * 10 + wk;
       bool done = false;
-      if (a->N_pad >= 64) {
+      if (a->N_pad >= 64 && ct == 4) {       // one wave per SIMD, 64 x 128 wave tiles
+        switch (key) {
+          case 141: done = t2f ? try_launch<1, 4, 1, 2, 10, true, 1, true, 4>(k, B, st) : try_launch<1, 4, 1, 2, 16, true, 1, false, 4>(k, B, st); break;
+          case 221: done = try_launch<2, 2, 1, 2, 8, true, 1, false, 4>(k, B, st); break;
+          case 411: done = try_launch<4, 1, 1, 2, 4, true, 1, false, 4>(k, B, st); break;
+          default: break;
+        }
+      } else if (a->N_pad >= 64) {
         switch (key) {
           case 221: done = try_launch<2, 2, 1, 2, 6, true, 2>(k, B, st); break;
           case 212: done = try_launch<2, 1, 2, 2, 4, true, 2>(k, B, st); break;
-          case 114: done = try_launch<1, 1, 4, 2, 12, false, 2>(k, B, st); break;
-          case 122: done = try_launch<1, 2, 2, 2, 10, false, 2>(k, B, st); break;
           case 411: done = try_launch<4, 1, 1, 2, 4, true, 2>(k, B, st); break;
           case 421: done = try_launch<4, 2, 1, 2, 2, true, 1>(k, B, st); break;
           case 141: done = t2f ? try_launch<1, 4, 1, 2, 6, true, 2, true>(k, B, st) : try_launch<1, 4, 1, 2, 6, true, 2>(k, B, st); break;
@@ -499,6 +522,8 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
   } else if (a->N_pad == 64) {
     if (cfg(1)) ok = (t2 && try_launch<1, 4, 1, 2, 6, true, 2, true>(k, B, st)) || try_launch<1, 4, 1, 2, 6, true, 2>(k, B, st);
   } else if (a->N_pad == 128) {
+    // (the one-wave-per-SIMD form - CT = 4, 64-channel x 128-pixel wave tiles, accumulators in AGPRs, CF_CONV3_CFG
+    //  "2,2,1,0,4" - is bit-identical and measured 97-123 us against 76-92 us here: DESIGN.md section 9)
     if (cfg(1)) ok = try_launch<2, 2, 1, 2, 6, true, 2>(k, B, st);   // (8 waves x 256 pixels measured 4 % slower here)
   } else {
     // 256+ channels: every 64-pixel tile streams the whole weight matrix from L2, which bounds these

@@ -38,8 +38,12 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4& 
   { unsigned th, tl; split2(b[2], b[3], th, tl); hi[3] = th; lo[3] = tl; }
 }
 
+// Weight fragment of (32-row tile rt, k-step ks, plane): [rt][ks][plane][64 lanes][8 f16].  Written as (tile base) +
+// 16 * lane so that with a wave-uniform rt / ks (callers read the wave index through readfirstlane) the base is scalar
+// arithmetic and ONE per-lane 32-bit offset register serves every weight load of a kernel.
 __device__ __forceinline__ const f16x8* wfrag16(const unsigned char* w, int rt, int ks, int plane, int n_ks, int lane) {
-  return reinterpret_cast<const f16x8*>(w + ((((size_t)rt * n_ks + ks) * 2 + plane) * 64 + lane) * 16);
+  const unsigned char* base = w + ((size_t)rt * n_ks + ks) * 2048 + plane * 1024;
+  return reinterpret_cast<const f16x8*>(base + (unsigned)lane * 16u);
 }
 
 }  // namespace

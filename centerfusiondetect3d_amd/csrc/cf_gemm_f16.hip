@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvF p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   extern __shared__ __attribute__((aligned(16))) cf_slot lds_slots[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: scalar tile / weight addressing)
   const int li = lane & 31, h = lane >> 5;
   const int wc = wave / WP, wp = wave % WP;
   const int m0 = cf_xcd_remap(blockIdx.x, gridDim.x) * PXB;   // consecutive pixel tiles share an XCD (L2)
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   // channel and the split - no floor / compare / branch in the K loop.
   f32x4* desc = reinterpret_cast<f32x4*>(smem + 2 * BUF);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: scalar tile / weight addressing)
   const int li = lane & 31, h = lane >> 5;
   const int wc = wave / WP, wp = wave % WP;
   // consecutive pixel tiles on ONE XCD: the gathered rows of a tile and of its neighbours then meet

@@ -55,7 +55,9 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 
 // fragment-packed weights: [row tile][k step][plane][lane][8 bf16]  -> byte offset of a wave's fragment
 __device__ __forceinline__ const bf16x8* wfrag(const unsigned char* w, int rt, int ks, int plane, int n_ks, int lane) {
-  return reinterpret_cast<const bf16x8*>(w + ((((size_t)rt * n_ks + ks) * 2 + plane) * 64 + lane) * 16);
+  // (tile base) + 16 * lane: with a wave-uniform rt / ks the base is scalar arithmetic (see wfrag16, cf_f16x3.h)
+  const unsigned char* base = w + ((size_t)rt * n_ks + ks) * 2048 + plane * 1024;
+  return reinterpret_cast<const bf16x8*>(base + (unsigned)lane * 16u);
 }
 
 // accumulator (lane = pixel ct*32+li, reg r = channel 64w + 32rt + (r&3) + 8(r>>2) + 4h) -> ReLU(acc + b)
@@ -868,7 +870,7 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   constexpr int NK = NKF + (PC ? 3 : 0);
   extern __shared__ __attribute__((aligned(16))) unsigned char xt[];
   const HeadTailK& p = q.t;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: scalar weight tile addressing)
   const int g = lane >> 4, c16 = lane & 15;
   const int per_img = q.tiles_x * q.tiles_y;
   const int per_head = per_img * (p.M / p.HW);

@@ -220,25 +220,34 @@ def nchw_to_nhwc(x, out=None, out_offset=0):
     return out
 
 
-_DCN_PACKS = {}       # (weight ptr, version, bias ptr, version, shape, device) -> PackedDcn; LRU of _DCN_PACK_KEYS
-_DCN_PACK_KEYS = 64
+_DCN_PACKS = {}       # id(weight) -> (weakref to weight, weight version, weakref to bias or None, bias version, PackedDcn)
+_DCN_PACK_KEYS = 64   # LRU bound
 
 
 def _packed_dcn(weight, bias):
-    """Pack (split fp16 hi / lo, MFMA fragment order: packing.pack_dcn_f16) ONCE per weight tensor and version - the
-    reference calls the operator with the same nn.Parameter every forward (dla.py:464-465)."""
+    """Pack (split fp16 hi / lo, MFMA fragment order: packing.pack_dcn_f16) ONCE per weight tensor OBJECT and version - the
+    reference calls the operator with the same nn.Parameter every forward (dla.py:464-465).  The entry holds weak
+    references and is valid only while they still point at the very tensors passed in: a data pointer or an id() alone
+    can be reused by another tensor after the first one is freed."""
+    import weakref
     from . import packing
-    key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version),
-           tuple(weight.shape), str(weight.device))
-    pd = _DCN_PACKS.pop(key, None)
-    if pd is None:
+    key = id(weight)
+    e = _DCN_PACKS.pop(key, None)
+    if e is not None:
+        wref, wver, bref, bver, pd = e
+        same_bias = (bias is None and bref is None) or (bref is not None and bref() is bias and bver == bias._version)
+        if not (wref() is weight and wver == weight._version and same_bias and pd.weight.device == weight.device):
+            e = None
+    if e is None:
         w = weight.detach().float().cpu()
         b = torch.zeros(w.shape[0]) if bias is None else bias.detach().float().cpu()
         pd = packing.pack_dcn_f16(w, b).to(weight.device)
-    _DCN_PACKS[key] = pd                          # re-inserted last: dict order is the LRU order
+        e = (weakref.ref(weight), weight._version, None if bias is None else weakref.ref(bias),
+             None if bias is None else bias._version, pd)
+    _DCN_PACKS[key] = e                           # re-inserted last: dict order is the LRU order
     while len(_DCN_PACKS) > _DCN_PACK_KEYS:
         _DCN_PACKS.pop(next(iter(_DCN_PACKS)))
-    return pd
+    return e[4]
 
 
 def _pair(v):

@@ -90,8 +90,17 @@ def test_weights_are_packed_once_per_version(dev):
     with torch.no_grad():
         w.mul_(2.0)                                        # in-place update bumps the version: re-packed
     b = ops.deform_conv2d(x, off, w, None, S, P, D, None)
-    assert len(ops._DCN_PACKS) == 2
+    assert len(ops._DCN_PACKS) == 1
     torch.testing.assert_close(b, 2 * a, rtol=1e-5, atol=1e-5)
+    # a DIFFERENT tensor that lands on the freed one's address (and id) must not hit the old entry
+    outs = []
+    for k in range(6):
+        w2 = rnd(32, 32, 3, 3, seed=10 + k).to(dev)
+        outs.append((ops.deform_conv2d(x, off, w2, None, S, P, D, None).cpu(), w2.cpu()))
+        del w2
+    from oracle import dcn_ref as _ref
+    for got, wk in outs:
+        torch.testing.assert_close(got, _ref.deform_conv2d(x.cpu(), off.cpu(), wk, None, S, P, D, None), rtol=1e-4, atol=1e-4)
 
 
 # ---- the known-answer tests of tests/test_oracle_dcn.py, through the HIP kernel (Cin padded to the kernel's 32) ----

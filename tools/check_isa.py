@@ -6,8 +6,9 @@ Two more invariants on the same listings:
   * coalesced epilogues (conv_f16x3 / dcn_f16x3 / conv3x3_f16x3): the lanes of a wave exchange their output tile through
     LDS; between the tile's ds_write group and the first ds_read behind it there must be an `s_waitcnt lgkmcnt(0)`
     (cf_wave_lds_sync, ADVICE r2) - checked behind the last v_mfma of every such kernel;
-  * no `scratch_` instruction between the first and the last v_mfma of a HOT kernel (spills inside the
-    MFMA loop); `--scratch-report` only lists them, the default fails on them for the kernels in NO_SCRATCH.
+  * no scratch at all (compiler-reported ScratchSize 0) in any instantiation of the kernels in NO_SCRATCH, and no
+    `scratch_` instruction inside an MFMA stream of any scanned kernel (VERDICT r2 item 3: spills in the MFMA loops);
+    `--scratch-report` only lists them.
     python tools/check_isa.py            -> exit status 0 if the invariants hold"""
 import os, re, subprocess, sys, tempfile
 
@@ -50,7 +51,21 @@ def violations(lines):
 
 EPILOGUE_KERNELS = ("conv_f16x3_kernel", "dcn_f16x3_kernel", "conv3x3_f16x3_kernel")
 # kernels whose MFMA loop must be free of scratch traffic (every instantiation the default path launches)
-NO_SCRATCH = ()       # filled in as the instantiations are cleaned up
+# kernels of the default path: NO instantiation may use scratch at all (ScratchSize 0 in the compiler's resource summary)
+NO_SCRATCH = ("head_patch16_kernel", "head_patch_kernel", "dcn_f16x3_kernel", "conv3x3_f16x3_kernel", "conv_f16x3_kernel")
+
+
+def scratch_sizes(asm):
+    """{mangled kernel name: ScratchSize} from the '; ScratchSize: N' lines the compiler prints behind each kernel."""
+    cur, out = None, {}
+    for ln in asm.split("\n"):
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            cur = m.group(1)
+        m = re.match(r"; ScratchSize: (\d+)", ln)
+        if m and cur:
+            out[cur] = int(m.group(1))
+    return out
 
 
 def epilogue_violations(lines):
@@ -112,7 +127,12 @@ def main():
             subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{os.path.join(ROOT, 'include')}",
                                    f"-I{CSRC}", "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, src)],
                                   stderr=subprocess.DEVNULL)
-            for name, lines in functions(open(out).read()).items():
+            asm = open(out).read()
+            for name, size in scratch_sizes(asm).items():
+                if size and any(k in name for k in NO_SCRATCH):
+                    print(f"{src}: {name[:90]}: ScratchSize {size} (spills)")
+                    failed |= not report_only
+            for name, lines in functions(asm).items():
                 if not any(k in name for k in kernels):
                     continue
                 if any(k in name for k in EPILOGUE_KERNELS):
@@ -125,7 +145,7 @@ def main():
                 sc = scratch_in_mfma_loop(lines)
                 if sc:
                     print(f"{src}: {name[:90]}: {len(sc)} scratch ops inside an MFMA stream (same basic block, MFMAs on both sides)")
-                    failed |= (not report_only) and any(k in name for k in NO_SCRATCH)
+                    failed |= not report_only
                 v = violations(lines)
                 if v is None:
                     print(f"{src}: {name[:80]}: no pinned region")
