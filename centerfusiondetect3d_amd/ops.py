@@ -235,7 +235,7 @@ def _packed_dcn(weight, bias):
     e = _DCN_PACKS.pop(key, None)
     if e is not None:
         wref, wver, bref, bver, pd = e
-        same_bias = (bias is None and bref is None) or (bref is not None and bref() is bias and bver == bias._version)
+        same_bias = (bref is None) if bias is None else (bref is not None and bref() is bias and bver == bias._version)
         if not (wref() is weight and wver == weight._version and same_bias and pd.weight.device == weight.device):
             e = None
     if e is None:
