@@ -347,16 +347,19 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   f32x4 cvs[NSET][WP][4][2];   // 4 corners x 8 channels
   f32x4 cws[NSET][WP];         // corner weights
   float cmks[NSET][WP];        // 16 * sigmoid(mask)
-  auto load_b = [&](int c, f32x4 (&cv)[WP][4][2], f32x4 (&cw)[WP], float (&cmk)[WP]) {
+  auto load_b_pair = [&](int c, int i, f32x4 (&cv)[WP][4][2], f32x4 (&cw)[WP], float (&cmk)[WP]) __attribute__((always_inline)) {
     const int tap = c / p.chunks_per_tap;
     const int c0 = (c - tap * p.chunks_per_tap) * 32 + (tid & 3) * 8;
-#pragma unroll
-    for (int i = 0; i < WP; ++i) {
+    {
       const int e = (((tid + 256 * i) >> 2) * 9 + tap) * 2;
       const f32x4 dA = desc[e];
       cw[i] = desc[e + 1];
       cmk[i] = dA[3];
+#ifdef CF_DCN_NOGATHER    // (dev timing experiment: every corner from one line - what the kernel costs without the gather)
+      const float* a0 = p.x + ((__float_as_int(dA[0]) & 0) + c0);
+#else
       const float* a0 = p.x + (__float_as_int(dA[0]) + c0);
+#endif
       const float* a1 = a0 + __float_as_int(dA[1]);
       const float* a2 = a0 + __float_as_int(dA[2]);
       const float* a3 = a2 + __float_as_int(dA[1]);
@@ -369,6 +372,10 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
       cv[i][3][0] = *reinterpret_cast<const f32x4*>(a3);
       cv[i][3][1] = *reinterpret_cast<const f32x4*>(a3 + 4);
     }
+  };
+  auto load_b = [&](int c, f32x4 (&cv)[WP][4][2], f32x4 (&cw)[WP], float (&cmk)[WP]) {
+#pragma unroll
+    for (int i = 0; i < WP; ++i) load_b_pair(c, i, cv, cw, cmk);
   };
   auto store_b = [&](unsigned char* buf, const f32x4 (&cv)[WP][4][2], const f32x4 (&cw)[WP], const float (&cmk)[WP]) {
 #pragma unroll
@@ -445,20 +452,96 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   store_b(smem, cvs[0], cws[0], cmks[0]);
   if (n_own > NSET) load_b(c_lo + NSET, cvs[0], cws[0], cmks[0]);
   __syncthreads();
-  // (no sched_barrier pinning here: it buys nothing in this kernel, and an earlier form with
-  //  exec-masked corner loads glitched with it when launched behind unrelated kernels, see
-  //  tools/stress_dcn.py)
+  // (an earlier form with exec-masked corner loads inside a pinned loop glitched when launched behind unrelated kernels,
+  //  tools/stress_dcn.py: the loads below are unconditional)
   auto iteration = [&](int j, f32x4 (&cv)[WP][4][2], f32x4 (&cw)[WP], float (&cmk)[WP]) {
     // MFMAs of chunk j; then chunk j+1 (held in set cv) is blended into the other buffer and the set is
     // re-requested for chunk j+1+NSET
     unsigned char* cur = smem + (j & 1) * BUF;
     unsigned char* nxt = smem + ((j + 1) & 1) * BUF;
     const int c = c_lo + j;
+    // Straight-line, hand-interleaved form for the single-pixel-group tiles (WP == 1: the 128- / 256-channel layers on the
+    // 28 x 50 and 14 x 25 maps): every MFMA is followed by one PIECE of the next chunk's staging (blend of 8 channels x 4
+    // corners, operand split + LDS store, the corner requests of the chunk after that) and a sched_barrier keeps it
+    // there, so the MFMA executes while the wave issues the piece; indices are clamped instead of branching and every
+    // load is unconditional (no exec-masked operand load inside a pinned loop).  Bit-identical to
+    // the plain form.  Measured (tools/bench_dcn.py, same box): 256 -> 128 at 28 x 50: 86.4 vs 93.0 us; the two-group tiles
+    // of the 64-channel layers LOSE with it (254 vs 212 us, 149 vs 131 us: every wait for a corner or an LDS fragment then
+    // also holds back the wave's next MFMA), so they keep the compiler's order.  CF_DCN_NOPIN: dev A/B.
+#ifndef CF_DCN_NOPIN
+    if constexpr (WP == 1)
+    {
+      f32x4 bv[2];                           // blended 8 channels of the pair in progress
+      u32x4 bhi, blo;
+      auto work = [&](int slot) __attribute__((always_inline)) {
+        constexpr int NSTG = 4 * WP;         // staging pieces: 4 per (pixel, unit) pair
+        if (slot < NSTG) {
+          const int i = slot >> 2, part = slot & 3;
+          if (part < 2) {                    // blend: 4 channels... x2 (one f32x4 half of the 8-channel unit), then the mask
+            f32x4 v = cw[i][0] * cv[i][0][part];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+              const f32x4 wk4 = {cw[i][k], cw[i][k], cw[i][k], cw[i][k]};
+              v = __builtin_elementwise_fma(wk4, cv[i][k][part], v);
+            }
+            bv[part] = v * cmk[i];
+          } else {                           // split to fp16 hi / lo; the second half also stores the unit
+            const int hf = part - 2;
+            { unsigned th, tl; split2(bv[hf][0], bv[hf][1], th, tl); bhi[2 * hf] = th; blo[2 * hf] = tl; }
+            { unsigned th, tl; split2(bv[hf][2], bv[hf][3], th, tl); bhi[2 * hf + 1] = th; blo[2 * hf + 1] = tl; }
+            if (hf == 1) {
+              const int pr = tid + 256 * i;
+              unsigned char* o = nxt + (pr >> 2) * FROWB + (pr & 3) * 16;
+              *reinterpret_cast<u32x4*>(o) = bhi;
+              *reinterpret_cast<u32x4*>(o + PLANE) = blo;
+            }
+          }
+        } else if (slot < NSTG + WP) {       // corner requests of chunk c + 1 + NSET into the set just consumed
+          load_b_pair(min(c + 1 + NSET, c_hi - 1), slot - NSTG, cv, cw, cmk);
+        }
+      };
+      auto kstep = [&](int s, const f16x8 (&ah)[RT], const f16x8 (&al)[RT]) __attribute__((always_inline)) {
+        f16x8 xh[2], xl[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const unsigned char* row = cur + (wp * 64 + ct * 32 + li) * FROWB + s * 32 + h * 16;
+          xh[ct] = *reinterpret_cast<const f16x8*>(row);
+          xl[ct] = *reinterpret_cast<const f16x8*>(row + PLANE);
+        }
+        int slot = s * 6 * RT;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rt], xh[ct], accs[rt][ct], 0, 0, 0);
+            work(slot++);
+            __builtin_amdgcn_sched_barrier(0);
+            accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rt], xl[ct], accs[rt][ct], 0, 0, 0);
+            work(slot++);
+            __builtin_amdgcn_sched_barrier(0);
+            accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rt], xh[ct], accm[rt][ct], 0, 0, 0);
+            work(slot++);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      };
+      kstep(0, wh[0], wl[0]);
+      load_w(wh[0], wl[0], min(2 * c + 2, 2 * c_hi - 2));
+      __builtin_amdgcn_sched_barrier(0);
+      kstep(1, wh[1], wl[1]);
+      load_w(wh[1], wl[1], min(2 * c + 3, 2 * c_hi - 1));
+      __syncthreads();
+      return;
+    }
+#endif
     mma_kstep(cur, 0, wh[0], wl[0]);
+#ifndef CF_DCN_NOWEIGHT   // (dev timing experiment: the weight stream's share of the texture path - DESIGN.md section 9)
     if (j + 1 < n_own) load_w(wh[0], wl[0], 2 * c + 2);
+#endif
     mma_kstep(cur, 1, wh[1], wl[1]);
     if (j + 1 < n_own) {
+#ifndef CF_DCN_NOWEIGHT
       load_w(wh[1], wl[1], 2 * c + 3);
+#endif
       store_b(nxt, cv, cw, cmk);
       if (j + 1 + NSET < n_own) load_b(c + 1 + NSET, cv, cw, cmk);
     }
