@@ -524,7 +524,10 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
   } else if (a->N_pad == 128) {
     // (the one-wave-per-SIMD form - CT = 4, 64-channel x 128-pixel wave tiles, accumulators in AGPRs, CF_CONV3_CFG
     //  "2,2,1,0,4" - is bit-identical and measured 97-123 us against 76-92 us here: DESIGN.md section 9)
-    if (cfg(1)) ok = try_launch<2, 2, 1, 2, 6, true, 2>(k, B, st);   // (8 waves x 256 pixels measured 4 % slower here)
+    // wide maps (3x896x1600: level 3 is 112 x 200): 8 x 16 tiles with a frame - the flat run's patch (R + 2W + 2 rows)
+    // no longer fits, and falling back to the slot kernel re-gathers every input 9 times
+    if (cfg(1)) ok = (t2 && try_launch<2, 2, 1, 2, 4, true, 2, true>(k, B, st)) || try_launch<2, 2, 1, 2, 6, true, 2>(k, B, st) ||
+                     try_launch<2, 2, 1, 2, 4, true, 2, true>(k, B, st);   // (8 waves x 256 pixels measured 4 % slower here)
   } else {
     // 256+ channels: every 64-pixel tile streams the whole weight matrix from L2, which bounds these
     // layers - with enough tiles to go round, 8 waves (two pixel groups per channel group, 128 pixels)
@@ -533,7 +536,9 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
     // smallest maps (level5, 14x25): 128 channels x 64 pixels per workgroup with K split over wave pairs
     // doubles the workgroup count and halves every wave's round chain (per-image rule, see above)
     if ((long)a->H * a->W <= 512 && cfg(2)) ok = try_launch<2, 1, 2, 2, 4, true, 2>(k, B, st);
-    if (!ok && cfg(1)) ok = (tiles128 >= 160 && try_launch<4, 2, 1, 2, 2, true, 1>(k, B, st)) || try_launch<4, 1, 1, 2, 4, true, 2>(k, B, st);
+    // (the tiled forms behind the flat ones: maps wider than ~60 / ~95 pixels, e.g. level 4 of a 3x896x1600 input)
+    if (!ok && cfg(1)) ok = (tiles128 >= 160 && (try_launch<4, 2, 1, 2, 2, true, 1>(k, B, st) || try_launch<4, 2, 1, 2, 2, true, 1, true>(k, B, st))) ||
+                            try_launch<4, 1, 1, 2, 4, true, 2>(k, B, st) || try_launch<4, 1, 1, 2, 2, true, 2, true>(k, B, st);
   }
   if (!ok) return cf_conv2d_f16x3(a, stream);
   return cf_check_launch("cf_conv3x3_f16x3");

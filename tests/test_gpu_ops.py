@@ -596,6 +596,11 @@ def test_conv2d_f16x3_fp32_level_accuracy(dev, B, Ci, Co, H, W, k, stride, act, 
     (1, 64, 64, 127, 126, 1, False, True),
     (16, 256, 256, 28, 50, 1, True, True),    # level4 at the bench size: 8 waves, 128-pixel runs
     (16, 128, 128, 56, 100, 1, True, True),   # level3 at the bench size: 8 waves, 256-pixel runs
+    (1, 128, 128, 112, 200, 1, True, True),   # level3 of a 3x896x1600 input: 8 x 16 tiles (the flat patch does not fit)
+    (2, 128, 128, 37, 150, 1, False, True),   # ... ragged tiles, tiled form as the fallback of the flat one
+    (1, 256, 256, 56, 100, 1, True, True),    # level4 of a 3x896x1600 input: 4 x 16 tiles, 4 waves
+    (8, 256, 256, 56, 100, 1, False, True),   # ... 8 waves (>= 160 tiles of 128 pixels), 8 x 16 tiles
+    (1, 512, 512, 30, 110, 1, False, True),   # wide 512-channel map
 ])
 def test_conv3x3_f16x3_patch(dev, B, Ci, Co, H, W, act, res, exact):
     """LDS-patch 3x3 kernel: fp32-level accuracy against float64, and - where the K loop is not split
