@@ -481,12 +481,20 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
     return slices % WK == 0;
   };
   // dev override (tools/bench_conv_cfg.py): CF_CONV3_CFG="WC,WP,WK[,T2]" forces one of the instantiated tilings
-  if (const char* force = getenv("CF_CONV3_CFG")) {
-    int wc = 0, wp = 0, wk = 0, t2f = 0, ct = 2;
-    if (sscanf(force, "%d,%d,%d,%d,%d", &wc, &wp, &wk, &t2f, &ct) >= 3 && cfg(wk)) {
+  static const int only_n = [] { const char* e = getenv("CF_CONV3_ONLY_N"); return e ? atoi(e) : 0; }();   // (dev: override one width only)
+  if (const char* force = (only_n == 0 || only_n == a->N_pad) ? getenv("CF_CONV3_CFG") : nullptr) {
+    int wc = 0, wp = 0, wk = 0, t2f = 0, ct = 2, rt = 2;
+    if (sscanf(force, "%d,%d,%d,%d,%d,%d", &wc, &wp, &wk, &t2f, &ct, &rt) >= 3 && cfg(wk)) {
       const int key = wc * 100 + wp * 10 + wk;
       bool done = false;
-      if (a->N_pad >= 64 && ct == 4) {       // one wave per SIMD, 64 x 128 wave tiles
+      if (a->N_pad >= 64 && ct == 4 && rt == 1) {   // 32-channel x 128-pixel wave tiles, two waves per SIMD: half the weight stream
+        switch (key) {
+          case 221: done = t2f ? try_launch<2, 2, 1, 1, 6, true, 2, true, 4>(k, B, st) : try_launch<2, 2, 1, 1, 12, true, 2, false, 4>(k, B, st); break;
+          case 411: done = t2f ? try_launch<4, 1, 1, 1, 4, true, 2, true, 4>(k, B, st) : try_launch<4, 1, 1, 1, 8, true, 2, false, 4>(k, B, st); break;
+          case 421: done = t2f ? try_launch<4, 2, 1, 1, 4, true, 1, true, 4>(k, B, st) : try_launch<4, 2, 1, 1, 4, true, 1, false, 4>(k, B, st); break;
+          default: break;
+        }
+      } else if (a->N_pad >= 64 && ct == 4) {       // one wave per SIMD, 64 x 128 wave tiles
         switch (key) {
           case 141: done = t2f ? try_launch<1, 4, 1, 2, 10, true, 1, true, 4>(k, B, st) : try_launch<1, 4, 1, 2, 16, true, 1, false, 4>(k, B, st); break;
           case 221: done = try_launch<2, 2, 1, 2, 8, true, 1, false, 4>(k, B, st); break;

@@ -244,6 +244,8 @@ def _packed_dcn(weight, bias):
         pd = packing.pack_dcn_f16(w, b).to(weight.device)
         e = (weakref.ref(weight), weight._version, None if bias is None else weakref.ref(bias),
              None if bias is None else bias._version, pd)
+    for k in [k for k, v in _DCN_PACKS.items() if v[0]() is None]:
+        del _DCN_PACKS[k]                         # weights that no longer exist: free their packed copies now
     _DCN_PACKS[key] = e                           # re-inserted last: dict order is the LRU order
     while len(_DCN_PACKS) > _DCN_PACK_KEYS:
         _DCN_PACKS.pop(next(iter(_DCN_PACKS)))
