@@ -296,6 +296,64 @@ def spawn_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def rehearse(args, world, rank, collective, json_fd):
+    """`--rehearse-cpu`: the multi-rank CONTROL FLOW of this file without a GPU - launcher, rendezvous, the
+    submit / wait pipeline of the overlapped all-gather, the drain inside the timed region, barrier fences, the MAX
+    over ranks, one JSON line from rank 0 on the saved descriptor, teardown - over gloo with a stand-in for the forward
+    (rows that carry their rank and step).  Measures nothing: the line says `"rehearsal": true, "value": null`.  It
+    exists because no multi-GPU node is available to the builder: `tests/test_bench_launcher.py` runs it at N = 2."""
+    import torch.distributed as dist
+    from centerfusiondetect3d_amd.distributed import DetectionGatherer, assume_equal_shards
+    assume_equal_shards(True)
+    if collective:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = args.batch
+    gatherer = DetectionGatherer(torch.device("cpu"), force_collective=args.force_collective)
+    pending, n_done = [], [0]
+
+    def step():
+        post = torch.full((B, 100, 54), float(1000 * rank + n_done[0]))
+        n_done[0] += 1
+        pending.append(gatherer.submit(post))
+        return pending.pop(0).wait() if len(pending) > 1 else None
+
+    def drain():
+        last = None
+        while pending:
+            last = pending.pop(0).wait()
+        return last
+
+    for _ in range(args.warmup):
+        step()
+    drain()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    det = drain()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    assert det.shape == (B * world, 100, 54)
+    last = args.warmup + args.steps - 1
+    for r in range(world):                     # rank-major, every rank's LAST step
+        assert bool((det[r * B:(r + 1) * B] == float(1000 * r + last)).all()), (rank, r)
+    t = torch.tensor([dt], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world,
+                                       "steps": args.steps, "warmup": args.warmup, "rehearsal": True,
+                                       "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "scaling": "weak",
+                                       "config": {"workload": "control-flow rehearsal on CPU (gloo), no forward",
+                                                  "global_batch": B * world}}) + "\n").encode())
+    if collective:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -319,6 +377,9 @@ def main():
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the RCCL process group and issue the per-step all-gather also at world size 1 (what a "
                          "rank of an N-GPU run does, on a one-GPU box)")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="no GPU, no measurement: run this file's multi-rank control flow over gloo with a stand-in forward "
+                         "(tests; the JSON line is marked as a rehearsal)")
     ap.add_argument("--end-to-end", action="store_true",
                     help="print the Detector.run-shaped line instead (uint8 frames + raw radar over PCIe -> final boxes)")
     args = ap.parse_args()
@@ -342,6 +403,11 @@ def main():
         print(f"bench.py[rank {rank}]: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree",
               file=sys.stderr)
         sys.exit(2)
+    import torch.distributed as dist
+    collective = world > 1 or args.force_collective
+    if args.rehearse_cpu:
+        rehearse(args, world, rank, collective, json_fd)
+        return
     n_dev = torch.cuda.device_count()          # (counting devices does not initialise HIP on this image)
     if local_rank >= n_dev:
         print(f"bench.py[rank {rank}]: needs GPU index {local_rank} but this node exposes {n_dev} device(s): "
@@ -351,8 +417,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    import torch.distributed as dist
-    collective = world > 1 or args.force_collective
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))

@@ -23,3 +23,40 @@ def test_launcher_and_flag_must_agree():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 2 and "disagree" in p.stderr
+
+
+def _one_json_line(stdout):
+    import json
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, stdout                       # stdout carries exactly the result line
+    return json.loads(lines[0])
+
+
+def test_multi_rank_control_flow_rehearsal_bare_spawn():
+    """`python bench.py --gpus 2 --rehearse-cpu`: launcher -> 2 ranks -> gloo rendezvous on 127.0.0.1 -> the overlapped
+    all-gather pipeline (submit / wait one step later / drain) -> barrier fences -> MAX over ranks -> ONE JSON line from
+    rank 0 -> teardown.  The code path RCCL ranks take, minus the GPU (no multi-GPU node exists for the builder)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-cpu", "--steps", "4",
+                        "--warmup", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _one_json_line(p.stdout)
+    assert d["rehearsal"] is True and d["value"] is None and d["n_gpus"] == 2 and d["config"]["global_batch"] == 32
+    assert d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
+
+
+def test_multi_rank_control_flow_rehearsal_under_the_drivers_launch_line():
+    """The driver's own form: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W (here N = 3, on CPU)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "3", "--steps", "3", "--warmup", "1", "--rehearse-cpu"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _one_json_line(p.stdout)
+    assert d["n_gpus"] == 3 and d["config"]["global_batch"] == 48 and d["rehearsal"] is True
