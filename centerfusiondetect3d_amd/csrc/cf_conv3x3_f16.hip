@@ -489,8 +489,8 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
       bool done = false;
       if (a->N_pad >= 64 && ct == 4 && rt == 1) {   // 32-channel x 128-pixel wave tiles, two waves per SIMD: half the weight stream
         switch (key) {
-          case 221: done = t2f ? try_launch<2, 2, 1, 1, 6, true, 2, true, 4>(k, B, st) : try_launch<2, 2, 1, 1, 12, true, 2, false, 4>(k, B, st); break;
-          case 411: done = t2f ? try_launch<4, 1, 1, 1, 4, true, 2, true, 4>(k, B, st) : try_launch<4, 1, 1, 1, 8, true, 2, false, 4>(k, B, st); break;
+          case 221: done = t2f && try_launch<2, 2, 1, 1, 6, true, 2, true, 4>(k, B, st); break;   // (the flat forms of these two spill)
+          case 411: done = t2f && try_launch<4, 1, 1, 1, 4, true, 2, true, 4>(k, B, st); break;
           case 421: done = t2f ? try_launch<4, 2, 1, 1, 4, true, 1, true, 4>(k, B, st) : try_launch<4, 2, 1, 1, 4, true, 1, false, 4>(k, B, st); break;
           default: break;
         }

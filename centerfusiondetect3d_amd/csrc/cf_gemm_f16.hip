@@ -363,6 +363,9 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
       const float* a1 = a0 + __float_as_int(dA[1]);
       const float* a2 = a0 + __float_as_int(dA[2]);
       const float* a3 = a2 + __float_as_int(dA[1]);
+#ifdef CF_DCN_NOLOAD      // (dev timing experiment: no corner requests at all behind the first chunk of a tile)
+      if (c > 1) return;
+#endif
       cv[i][0][0] = *reinterpret_cast<const f32x4*>(a0);
       cv[i][0][1] = *reinterpret_cast<const f32x4*>(a0 + 4);
       cv[i][1][0] = *reinterpret_cast<const f32x4*>(a1);
