@@ -111,6 +111,9 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
   f32x4 raw[NU];
   auto load_patch = [&](int r, int lo, int hi) {
     const int c0 = r * 16 * WK;
+#ifdef CF_CONV3_NOPATCH   // (dev timing experiment: the patch is fetched once per tile, later rounds re-split the same rows)
+    if (r > 0) return;
+#endif
 #pragma unroll
     for (int it = 0; it < NU; ++it) {
       if (it < lo || it >= hi) continue;
@@ -178,6 +181,9 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
   // 32-bit offset register serves every weight load of the kernel
   const unsigned lane16 = (unsigned)lane * 16u;
   auto load_w = [&](f16x8 (&dh)[RT], f16x8 (&dl)[RT], int ks) {
+#ifdef CF_CONV3_NOWEIGHT  // (dev timing experiment: weight fragments fetched for the first three taps only)
+    if (ks > wk * 9 + 2) return;
+#endif
     ks = min(ks, ks_last);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
