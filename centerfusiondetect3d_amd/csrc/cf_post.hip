@@ -16,7 +16,8 @@ namespace {
 constexpr int TOPK_THREADS = 256;   // slice kernel
 constexpr int TOPK_MERGE_THREADS = 1024;
 constexpr int TOPK_CAP = 4096;      // candidate keys kept in LDS (32 KiB)
-constexpr int TOPK_SLICES = 16;     // workgroups per image in the slice pass
+constexpr int TOPK_SLICES = 16;     // workgroups per image in the slice pass (32: slice pass 43 -> 26 us, but the merge of
+                                    // twice as many lists 12 -> 35 us)
 constexpr int TOPK_MAXK = 256;      // K <= number of threads of the slice kernel
 
 __device__ __forceinline__ uint32_t f2u(float f) {  // order-preserving float -> uint (-0 and +0 tie, as they compare)
@@ -76,6 +77,16 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ heat
   }
 }
 
+// (see C below) keys[0..n) unique, n <= blockDim.x * 4: out[r] = the key of rank r (descending) for r < K.
+__device__ __forceinline__ void rank_select_desc(const uint64_t* keys, int n, int K, uint64_t* __restrict__ out) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint64_t mine = keys[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += keys[j] > mine ? 1 : 0;     // (same address across the wave: LDS broadcast)
+    if (rank < K) out[rank] = mine;
+  }
+}
+
 // Pass 1: top-K of one SLICE of one image (TOPK_SLICES workgroups per image), as sorted 64-bit keys
 // (order-preserving score bits << 32 | ~flat_index), i.e. ordered by (score desc, flat index asc)
 // == (score desc, class asc, pixel asc).  Every element of the image's top-K is in its slice's
@@ -85,7 +96,9 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ heat
 //  B. elements > L are collected into LDS; if fewer than K, the missing ones are the elements == L
 //     with the smallest indices, taken by an index-ordered block scan (the common case on real heat
 //     maps: the clamp plateau at 1e-4 ties everywhere);
-//  C. the <= 4096 candidates are bitonic-sorted.
+//  C. the candidates are ordered: up to 1024 of them by RANK COUNTING (every key counts the keys above it - the keys
+//     are unique - and the ones ranked below K are written straight to their place: one pass over LDS, one barrier,
+//     against the ~45 barrier-separated passes of a bitonic sort), more than that (adversarial inputs) by the sort.
 // If more than 4096 elements exceed L (adversarial input), the exact K-th value is found by a
 // 4 x 8-bit radix select and step B is repeated with it.
 template <bool NMS>
@@ -117,28 +130,60 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* _
   //  suppressed non-negative element becomes 0 <= raw, so raw <= bound settles it without the 9
   //  loads; negative values, which suppression would RAISE to -0, always take the full path)
   uint32_t lmax = 0;
-  for (int i = lo + tid; i < hi; i += TOPK_THREADS) {
-    const float v = img[i];
-    if (!NMS || f2u(v) > lmax || v < 0.0f) lmax = max(lmax, f2u(peak_value<NMS>(img, i, H, W)));
+  {
+    int i = lo + tid;
+    for (; i + 3 * TOPK_THREADS < hi; i += 4 * TOPK_THREADS) {      // four independent loads in flight
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = img[i + u * TOPK_THREADS];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (!NMS || f2u(v[u]) > lmax || v[u] < 0.0f)
+          lmax = max(lmax, NMS ? f2u(peak_value<NMS>(img, i + u * TOPK_THREADS, H, W)) : f2u(v[u]));
+    }
+    for (; i < hi; i += TOPK_THREADS) {
+      const float v = img[i];
+      if (!NMS || f2u(v) > lmax || v < 0.0f) lmax = max(lmax, f2u(peak_value<NMS>(img, i, H, W)));
+    }
   }
-  keys[tid] = lmax;
+  // K-th largest of the 256 local maxima by rank counting (ties ranked by thread id): one barrier instead of a sort
+  uint32_t* lm = reinterpret_cast<uint32_t*>(keys);
+  lm[tid] = lmax;
   __syncthreads();
-  bitonic_sort_desc(keys, TOPK_THREADS);
-  uint32_t L = (uint32_t)keys[K - 1];
+  {
+    int rank = 0;
+    for (int j = 0; j < TOPK_THREADS; ++j) {
+      const uint32_t o = lm[j];
+      rank += (o > lmax || (o == lmax && j < tid)) ? 1 : 0;
+    }
+    if (rank == K - 1) s_sel[0] = lmax;
+  }
+  __syncthreads();
+  uint32_t L = s_sel[0];
   __syncthreads();
 
   // ---- B: collect everything strictly above the bound
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (tid == 0) s_gt = 0;
     __syncthreads();
-    for (int i = lo + tid; i < hi; i += TOPK_THREADS) {
-      const float v = img[i];
-      uint32_t u = f2u(v);
-      if (NMS && (u > L || v < 0.0f)) u = f2u(peak_value<NMS>(img, i, H, W));
-      if (u > L) {
-        const uint32_t pos = atomicAdd(&s_gt, 1u);
-        if (pos < TOPK_CAP) keys[pos] = ((uint64_t)u << 32) | (uint32_t)(~(uint32_t)i);
+    {
+      auto take = [&](int i, float v) {
+        uint32_t u = f2u(v);
+        if (NMS && (u > L || v < 0.0f)) u = f2u(peak_value<NMS>(img, i, H, W));
+        if (u > L) {
+          const uint32_t pos = atomicAdd(&s_gt, 1u);
+          if (pos < TOPK_CAP) keys[pos] = ((uint64_t)u << 32) | (uint32_t)(~(uint32_t)i);
+        }
+      };
+      int i = lo + tid;
+      for (; i + 3 * TOPK_THREADS < hi; i += 4 * TOPK_THREADS) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = img[i + u * TOPK_THREADS];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) take(i + u * TOPK_THREADS, v[u]);
       }
+      for (; i < hi; i += TOPK_THREADS) take(i, img[i]);
     }
     __syncthreads();
     if (s_gt <= TOPK_CAP) break;
@@ -198,6 +243,11 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* _
     }
     total = K;
   }
+  if (total <= 4 * TOPK_THREADS) {
+    __syncthreads();
+    rank_select_desc(keys, total, K, out);
+    return;
+  }
   int P = 1;
   while (P < total) P <<= 1;
   for (int i = total + tid; i < P; i += TOPK_THREADS) keys[i] = 0;
@@ -211,16 +261,33 @@ __global__ __launch_bounds__(TOPK_MERGE_THREADS) void topk_merge_kernel(const ui
                                                                         int K, int HW, float* __restrict__ scores,
                                                                         int32_t* __restrict__ inds,
                                                                         int32_t* __restrict__ classes) {
-  __shared__ uint64_t keys[TOPK_SLICES * TOPK_MAXK];
+  extern __shared__ __attribute__((aligned(16))) uint64_t keys[];      // TOPK_SLICES * K keys
+  __shared__ uint64_t best[TOPK_MAXK];
   const int tid = threadIdx.x, total = TOPK_SLICES * K;
-  int P = 1;
-  while (P < total) P <<= 1;
   const uint64_t* src = in_keys + (size_t)blockIdx.x * total;
-  for (int i = tid; i < P; i += TOPK_MERGE_THREADS) keys[i] = i < total ? src[i] : 0ull;
+  for (int i = tid; i < total; i += TOPK_MERGE_THREADS) keys[i] = src[i];
   __syncthreads();
-  bitonic_sort_desc(keys, P);
+  // every list is sorted (descending, keys unique over the image): the rank of an element is its position in its own
+  // list plus, for every other list, the number of keys above it - a binary search each; ranks below K are the output
+  for (int i = tid; i < total; i += TOPK_MERGE_THREADS) {
+    const int sl = i / K, pos = i - sl * K;
+    const uint64_t mine = keys[i];
+    int rank = pos;
+    for (int o = 0; o < TOPK_SLICES && rank < K; ++o) {
+      if (o == sl) continue;
+      const uint64_t* lst = keys + o * K;
+      int lo = 0, hi = K;                      // first position whose key is NOT above mine
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (lst[mid] > mine) lo = mid + 1; else hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < K) best[rank] = mine;
+  }
+  __syncthreads();
   for (int j = tid; j < K; j += TOPK_MERGE_THREADS) {
-    const uint64_t key = keys[j];
+    const uint64_t key = best[j];
     const uint32_t idx = ~(uint32_t)key;
     const int c = (int)(idx / (uint32_t)HW);
     scores[(size_t)blockIdx.x * K + j] = u2f((uint32_t)(key >> 32));
@@ -948,7 +1015,10 @@ extern "C" int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int 
     hipLaunchKernelGGL(topk_slice_kernel<true>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys);
   else
     hipLaunchKernelGGL(topk_slice_kernel<false>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys);
-  hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(TOPK_MERGE_THREADS), 0, st, keys, K, H * W, scores, inds, classes);
+  const size_t merge_lds = (size_t)TOPK_SLICES * K * sizeof(uint64_t);
+  static CfLdsLimit merge_limit;
+  merge_limit.ensure(topk_merge_kernel, merge_lds, 65536);
+  hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(TOPK_MERGE_THREADS), merge_lds, st, keys, K, H * W, scores, inds, classes);
   return cf_check_launch("cf_topk_peaks");
 }
 
