@@ -121,6 +121,9 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     }
   };
   auto store_patch = [&](unsigned char* buf, int lo, int hi) {
+#ifdef CF_CONV3_NOSTAGE   // (dev timing experiment: no operand split / LDS store behind the first patch)
+    if (buf != smem) return;
+#endif
     int tid_s = threadIdx.x;                 // (laundered: the NU destination addresses are re-derived per call - 3 ALU
     asm volatile("" : "+v"(tid_s));          //  instructions each - instead of living in registers / scratch all loop long)
 #pragma unroll
@@ -257,7 +260,9 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
       }
     }
     if (more) store_patch(nxt, NH0, NU);
+#ifndef CF_CONV3_NOBARRIER   // (dev timing experiment: results are garbage without it)
     __syncthreads();
+#endif
     PROF_MARK(2)
   }
 
