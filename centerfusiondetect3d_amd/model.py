@@ -692,8 +692,11 @@ class DLASeg(nn.Module):
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
         self.lanes = True        # small batches: the IDA projections on a side stream beside the node chain (_Plan.ida)
-        self.streams = 2         # > 1 (and batch >= 4 * streams): backbone + neck as that many sub-batches on
+        self.streams = 2         # > 1 (and batch >= min_sub_batch * streams): backbone + neck as that many sub-batches on
                                  # concurrent HIP streams with their own plans; heads on the caller's stream
+        self.min_sub_batch = 6   # ... and only when a sub-batch keeps at least this many frames: measured (tools/
+                                 # bench_small_batch.py, ms per forward + decode, one stream vs two): B=8 5.28 vs 5.91,
+                                 # B=12 7.72 vs 6.86, B=16 9.16 vs 8.61 - four-frame trunks lose to one eight-frame forward
         self.use_graph = False   # replay the forward as ONE captured HIP graph (inputs / outputs staged through
                                  # static buffers) instead of ~100 launches from Python (_forward_graph)
         self.stem_fused = True   # with conv_f16: base_layer + level0 + level1 in one launch (cf_stem.hip)
@@ -907,7 +910,7 @@ class DLASeg(nn.Module):
             return self._forward_eager(x, pc_dep, calib, B, H, W, dev, sid)
 
     def _forward_eager(self, x, pc_dep, calib, B, H, W, dev, sid, store=None):
-        if self.streams > 1 and B % self.streams == 0 and B // self.streams >= 4:
+        if self.streams > 1 and B % self.streams == 0 and B // self.streams >= self.min_sub_batch:
             return self._forward_concurrent(x, pc_dep, calib, B, H, W, dev, sid, store)
         plan = self._plan((B, H, W, dev, sid), lambda: _Plan(self, B, H, W, dev), store)
         return plan.run(self, x, pc_dep, calib)

@@ -391,6 +391,7 @@ def test_two_stream_forward_equals_single_stream(dev):
         m.streams = 1
         one = m(xd, pc_dep=pd, calib=cd)
         det1, _ = decode_packed([dict(one[0])], (112, 200), 100)     # (decode renames rotation2 in the dict it gets)
+        m.min_sub_batch = 4                                       # (the default, 6, would not split 16 frames four ways)
         for n_streams in (2, 4):
             m.streams = n_streams
             for rep in range(3):
@@ -406,11 +407,13 @@ def test_two_stream_forward_equals_single_stream(dev):
         assert any(isinstance(k, tuple) and "trunk" in k for k in m._plans)     # the split path really ran
     mc = _model(False, dev, (256, 416))
     xc = cases.model_inputs(8, 256, 416, seed=46, radar=False)[0].to(dev)
+    mc.min_sub_batch = 4
     with torch.no_grad():
         mc.streams = 1
         a = mc(xc)[0]
         mc.streams = 2
         b = mc(xc)[0]
+    assert any("trunk" in k for k in mc._plans)
     for k in a:
         if k != "calib":
             assert torch.equal(a[k], b[k]), k
