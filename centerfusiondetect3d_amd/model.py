@@ -694,7 +694,7 @@ class DLASeg(nn.Module):
         self.lanes = True        # small batches: the IDA projections on a side stream beside the node chain (_Plan.ida)
         self.streams = 2         # > 1 (and batch >= min_sub_batch * streams): backbone + neck as that many sub-batches on
                                  # concurrent HIP streams with their own plans; heads on the caller's stream
-        self.min_sub_batch = 6   # ... and only when a sub-batch keeps at least this many frames: measured (tools/
+        self.min_sub_batch = 6   # ... and only when a sub-batch keeps at least this many 448x800-frame equivalents: measured (tools/
                                  # bench_small_batch.py, ms per forward + decode, one stream vs two): B=8 5.28 vs 5.91,
                                  # B=12 7.72 vs 6.86, B=16 9.16 vs 8.61 - four-frame trunks lose to one eight-frame forward
         self.use_graph = False   # replay the forward as ONE captured HIP graph (inputs / outputs staged through
@@ -910,7 +910,8 @@ class DLASeg(nn.Module):
             return self._forward_eager(x, pc_dep, calib, B, H, W, dev, sid)
 
     def _forward_eager(self, x, pc_dep, calib, B, H, W, dev, sid, store=None):
-        if self.streams > 1 and B % self.streams == 0 and B // self.streams >= self.min_sub_batch:
+        # (min_sub_batch counts 448 x 800 frames: a sub-batch of a larger input carries proportionally more work)
+        if self.streams > 1 and B % self.streams == 0 and (B // self.streams) * H * W >= self.min_sub_batch * 448 * 800:
             return self._forward_concurrent(x, pc_dep, calib, B, H, W, dev, sid, store)
         plan = self._plan((B, H, W, dev, sid), lambda: _Plan(self, B, H, W, dev), store)
         return plan.run(self, x, pc_dep, calib)
