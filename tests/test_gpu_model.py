@@ -546,6 +546,8 @@ def test_plan_cache_is_an_lru_and_frees_evicted_buffers(dev):
     x, pc_dep, calib = cases.model_inputs(8, H, W, seed=5, radar=True)
     xd, pd, cdv = x.to(dev), pc_dep.to(dev), calib.to(dev)
     mem, first = [], {}
+    import gc
+    gc.collect()                                   # models of earlier tests: their memory must not be freed under our feet
     torch.cuda.synchronize()
     base = torch.cuda.memory_allocated()
     with torch.no_grad():
