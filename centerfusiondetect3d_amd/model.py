@@ -248,7 +248,7 @@ class _Plan:
         self.n_events = 0
         # two-lane issue of the neck for small batches (a launch cannot fill the chip there); never with the timed /
         # graph paths, which want one stream
-        self.use_lanes = bool(model.lanes) and part != "heads" and B * (H // 4) * (W // 4) <= 4 * 112 * 200
+        self.use_lanes = bool(model.lanes) and part != "heads" and B * (H // 4) * (W // 4) <= model.lanes_max_frames * 112 * 200
         self.keep = []           # keeps arg blocks / buffers alive
         self.bytes = 0
         self.step_index = {}     # conv name -> index in self.steps
@@ -692,6 +692,7 @@ class DLASeg(nn.Module):
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
         self.lanes = True        # small batches: the IDA projections on a side stream beside the node chain (_Plan.ida)
+        self.lanes_max_frames = 4  # ... up to this many 448x800-frame equivalents per plan
         self.streams = 2         # > 1 (and batch >= min_sub_batch * streams): backbone + neck as that many sub-batches on
                                  # concurrent HIP streams with their own plans; heads on the caller's stream
         self.min_sub_batch = 6   # ... and only when a sub-batch keeps at least this many 448x800-frame equivalents: measured (tools/
