@@ -290,3 +290,36 @@ def test_stream_probe_tells_shared_queue_from_concurrent(dev):
     found = [(i, j) for i in range(4) for j in range(i + 1, 4) if M._concurrent(lib, s[i], s[j])[0]]
     assert found, "no two of four fresh streams run concurrently"
     assert lib.cf_spin_us(0, None) != 0 and lib.cf_spin_us(200000, None) != 0        # bounded by contract
+
+
+def test_run_pipelined_equals_run(dev):
+    """Detector.run_pipelined (batch i+1's copy / warp / radar ingest on a feed stream beside batch i's forward, results
+    fetched one batch behind) yields, in order, exactly what Detector.run returns batch by batch - also with batches of
+    different sizes and with the host-side merge on."""
+    from centerfusiondetect3d_amd import Detector, centerfusion_middle_config
+    H, W = 128, 160
+    cfg = centerfusion_middle_config((H, W))
+    det = Detector(cfg, device=dev)
+    det.model.load_state_dict(cases.tuned_state_dict(radar=True, seed=0), strict=True)
+    calib = np.concatenate([cd.NUSC_K, np.zeros((3, 1))], axis=1)
+    batches = []
+    for i, B in enumerate((2, 3, 1, 2)):
+        rs = np.random.RandomState(40 + i)
+        frames = torch.from_numpy(rs.randint(0, 256, (B, 900, 1600, 3)).astype(np.uint8)).pin_memory()
+        infos = [dict(calib=calib.tolist(), camera_intrinsic=cd.NUSC_K.tolist(), width=1600, height=900)] * B
+        sweeps = [cd._sweep(np.random.RandomState(400 + 10 * i + b), 60 + 20 * b) for b in range(B)]
+        batches.append((frames, infos, sweeps))
+    with torch.no_grad():
+        ref = [det.run(*b) for b in batches]
+        got = list(det.run_pipelined(iter(batches)))
+        assert len(got) == len(ref)
+        for r, g in zip(ref, got):
+            assert torch.equal(r["post"], g["post"])
+            for k in r["outputs"][0]:
+                assert torch.equal(r["outputs"][0][k], g["outputs"][0][k]), k
+            assert len(r["predictBoxes"]) == len(g["predictBoxes"])
+            for k in r["detects"]:
+                assert torch.equal(r["detects"][k], g["detects"][k])
+        assert list(det.run_pipelined(iter([]))) == []
+        one = list(det.run_pipelined(iter(batches[:1]), merge=False))
+        assert len(one) == 1 and torch.equal(one[0]["post"], ref[0]["post"])
