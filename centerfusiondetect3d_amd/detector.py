@@ -113,8 +113,8 @@ class Detector(object):
             radar_pc = [radar_pc] if radar_pc is not None else None
         return imgInput, img_info, radar_pc
 
-    def _finish(self, outputs, post, metas, merge):
-        ret = {"outputs": outputs, "post": post, "metas": metas}
+    def _finish(self, outputs, post, metas, img_infos, merge):
+        ret = {"outputs": outputs, "post": post, "metas": metas, "img_infos": img_infos}
         if merge:
             detects = {k: v.cpu() for k, v in unpack_post(post).items()}
             ret["detects"] = detects
@@ -143,14 +143,14 @@ class Detector(object):
                     pre = self.pre_process(imgInput, img_info, radar_pc)
                     ev = torch.cuda.Event()
                     ev.record(feed)
-                return pre, ev
+                return pre + (img_info,), ev
 
             batch = next(it, None)
             if batch is None:
                 return
             staged, pending = stage(batch), None
             while staged is not None:
-                (images, pc_dep, metas, calibs), ev = staged
+                (images, pc_dep, metas, calibs, infos), ev = staged
                 main.wait_event(ev)
                 for t in (images, pc_dep, calibs):
                     if t is not None:
@@ -160,15 +160,16 @@ class Detector(object):
                 staged = stage(batch) if batch is not None else None                # batch i+1: beside it, on `feed`
                 if pending is not None:
                     yield self._finish(*pending, merge)                              # batch i-1: host side
-                pending = (outputs, post, metas)
+                pending = (outputs, post, metas, infos)
             yield self._finish(*pending, merge)
 
     def run(self, imgInput, img_info=None, radar_pc=None, merge=True):
         """imgInput: (H,W,3) uint8 ndarray, a list of them, or a (B,H,W,3) uint8 tensor; img_info: dict or list of
         dicts (`calib`, and for radar `camera_intrinsic`, `width`, `height`); radar_pc: (R,N) array or list.
-        -> {"outputs", "post" (B,K,54) device, "detects" (dict of host tensors), "predictBoxes"}."""
+        -> {"outputs", "post" (B,K,54) device, "metas", "img_infos" (the batch's own, as a list), "detects" (dict of host
+        tensors), "predictBoxes"}."""
         imgInput, img_info, radar_pc = self._as_batch(imgInput, img_info, radar_pc)
         with torch.cuda.device(self.device):
             images, pc_dep, metas, calibs = self.pre_process(imgInput, img_info, radar_pc)
             outputs, post = self.process(images, calibs, pc_dep, metas[0])
-        return self._finish(outputs, post, metas, merge)
+        return self._finish(outputs, post, metas, img_info, merge)
