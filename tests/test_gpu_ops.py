@@ -217,6 +217,23 @@ def test_topk_overflow_path_and_odd_shapes(dev):
     _check_topk(dev, neg, 50, False)
 
 
+@pytest.mark.parametrize("n_big", [300, 3000, 6000])
+def test_topk_candidate_counts_across_the_three_ordering_paths(dev, n_big):
+    """A slice (14,000 elements at 10 x 112 x 200, scanned by 256 threads with stride 256) whose large values all sit
+    in 90 of the 256 lanes: the K-th largest LOCAL maximum is then small and every large value is a candidate -
+    300 of them are ordered by rank counting, 3,000 by the bitonic sort (> 1,024), 6,000 (> 4,096, the LDS capacity)
+    go through the radix select first.  All three must give the oracle's top-K, also behind the NMS."""
+    g = torch.Generator().manual_seed(n_big)
+    heat = torch.rand(2, 10, 112, 200, generator=g) * 0.1
+    flat = heat[1].view(-1)                                       # image 1, slice 0 = its first 14,000 elements
+    lanes = torch.arange(14000)
+    pool = lanes[lanes % 256 < 90]
+    pick = pool[torch.randperm(pool.numel(), generator=g)[:n_big]] if n_big <= pool.numel() else pool
+    flat[pick] = torch.rand(pick.numel(), generator=g) * 0.4 + 0.5
+    _check_topk(dev, heat, 100, False)
+    _check_topk(dev, heat, 100, True)
+
+
 # --------------------------------------------------------------------------------------- frustum
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_frustum_bit_exact_vs_reference_golden(dev, golden_dir, seed):
