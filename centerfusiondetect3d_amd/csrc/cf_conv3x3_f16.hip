@@ -232,7 +232,11 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
+#ifdef CF_ONESET   // (dev timing experiment: all three products into ONE accumulator set - fails the float64 RMS gate)
+          accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t % 3][rt], xh[t & 1][ct], accm[rt][ct], 0, 0, 0);
+#else
           accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t % 3][rt], xh[t & 1][ct], accs[rt][ct], 0, 0, 0);
+#endif
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -242,7 +246,11 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
+#ifdef CF_ONESET
+          accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t % 3][rt], xl[ct], accm[rt][ct], 0, 0, 0);
+#else
           accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t % 3][rt], xl[ct], accs[rt][ct], 0, 0, 0);
+#endif
       // tap t+3 of this round, or tap t-6 of the next one (same set either way)
       load_w(wh[t % 3], wl[t % 3], t + 3 < 9 ? ks0 + t + 3 : ks0 + 9 * WK + t - 6);
       if (DB && t == 3 && more) {            // first half of the next patch: split + store, then request the rest
@@ -498,6 +506,16 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
     if (sscanf(force, "%d,%d,%d,%d,%d,%d", &wc, &wp, &wk, &t2f, &ct, &rt) >= 3 && cfg(wk)) {
       const int key = wc * 100 + wp * 10 + wk;
       bool done = false;
+#ifdef CF_ONESET
+      if (a->N_pad >= 64 && ct == 4 && rt == 2) {   // 64-channel x 128-pixel wave tiles at TWO waves per SIMD (one accumulator set)
+        switch (key) {
+          case 141: done = t2f && try_launch<1, 4, 1, 2, 10, true, 2, true, 4>(k, B, st); break;
+          case 221: done = t2f ? try_launch<2, 2, 1, 2, 6, true, 2, true, 4>(k, B, st) : try_launch<2, 2, 1, 2, 8, true, 2, false, 4>(k, B, st); break;
+          case 411: done = t2f ? try_launch<4, 1, 1, 2, 4, true, 2, true, 4>(k, B, st) : try_launch<4, 1, 1, 2, 4, true, 2, false, 4>(k, B, st); break;
+          default: break;
+        }
+      } else
+#endif
       if (a->N_pad >= 64 && ct == 4 && rt == 1) {   // 32-channel x 128-pixel wave tiles, two waves per SIMD: half the weight stream
         switch (key) {
           case 221: done = t2f && try_launch<2, 2, 1, 1, 6, true, 2, true, 4>(k, B, st); break;   // (the flat forms of these two spill)
