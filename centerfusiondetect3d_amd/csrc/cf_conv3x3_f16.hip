@@ -506,6 +506,15 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
     if (sscanf(force, "%d,%d,%d,%d,%d,%d", &wc, &wp, &wk, &t2f, &ct, &rt) >= 3 && cfg(wk)) {
       const int key = wc * 100 + wp * 10 + wk;
       bool done = false;
+      if (a->N_pad >= 64 && ct == 1) {              // half-size pixel tiles (32 pixels per wave): small grids, see below
+        switch (key) {
+          case 221: done = try_launch<2, 2, 1, 2, 4, true, 2, false, 1>(k, B, st); break;
+          case 411: done = try_launch<4, 1, 1, 2, 4, true, 2, false, 1>(k, B, st); break;
+          case 212: done = try_launch<2, 1, 2, 2, 4, true, 2, false, 1>(k, B, st); break;
+          case 141: done = t2f ? try_launch<1, 4, 1, 2, 4, true, 2, true, 1>(k, B, st) : try_launch<1, 4, 1, 2, 6, true, 2, false, 1>(k, B, st); break;
+          default: break;
+        }
+      } else
 #ifdef CF_ONESET
       if (a->N_pad >= 64 && ct == 4 && rt == 2) {   // 64-channel x 128-pixel wave tiles at TWO waves per SIMD (one accumulator set)
         switch (key) {
@@ -547,8 +556,18 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
                                                   //  summation order, and a shard of a batch has to
                                                   //  reproduce the full batch bit for bit)
   const bool t2 = big && tiles_fit(a->H, a->W);
+  // SMALL GRIDS (small batches): while a launch of half-size pixel tiles (CT = 1: 32 pixels per wave) still fits the chip
+  // in one round - at most one workgroup per CU - it is a third faster than the default tile, whose handful of
+  // workgroups each walk twice the MFMAs per round on an otherwise empty chip (bs=1, 128 -> 128 at 56x100: 16.6 vs
+  // 25.8 us; 256 -> 256 at 28x50: 27.5 vs 41.2 us; 512 -> 512 at 14x25: 31.8 vs 43.2 us; at 262 workgroups the gain is
+  // gone).  The tile shape changes no sum (same K order, same WK): results are bit-identical, so this MAY depend on the
+  // batch size; the patch is tiled (8 x 16) whatever the map - tile quantisation costs nothing on an empty chip.
+  const long tiles8x16 = (long)((a->H + 7) / 8) * ((a->W + 15) / 16) * B;
+  auto one_round = [&](long wgs) { return wgs <= 256; };
   if (a->N_pad == 32) {
-    if (big && cfg(1)) {
+    if (big && cfg(1) && one_round(tiles8x16)) ok = try_launch<1, 4, 1, 1, 4, true, 2, true, 1>(k, B, st);
+    if (ok) {
+    } else if (big && cfg(1)) {
       ok = (t2 && try_launch<1, 4, 1, 1, 6, true, 2, true>(k, B, st)) || try_launch<1, 4, 1, 1, 8, true, 2>(k, B, st) ||
            try_launch<1, 4, 1, 1, 12, true, 1>(k, B, st);
     } else {
@@ -557,13 +576,15 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
       if (!ok && cfg(1)) ok = try_launch<1, 4, 1, 1, 12, true, 1>(k, B, st);
     }
   } else if (a->N_pad == 64) {
-    if (cfg(1)) ok = (t2 && try_launch<1, 4, 1, 2, 6, true, 2, true>(k, B, st)) || try_launch<1, 4, 1, 2, 6, true, 2>(k, B, st);
+    if (cfg(1)) ok = (one_round(tiles8x16) && try_launch<1, 4, 1, 2, 4, true, 2, true, 1>(k, B, st)) ||
+                     (t2 && try_launch<1, 4, 1, 2, 6, true, 2, true>(k, B, st)) || try_launch<1, 4, 1, 2, 6, true, 2>(k, B, st);
   } else if (a->N_pad == 128) {
     // (the one-wave-per-SIMD form - CT = 4, 64-channel x 128-pixel wave tiles, accumulators in AGPRs, CF_CONV3_CFG
     //  "2,2,1,0,4" - is bit-identical and measured 97-123 us against 76-92 us here: DESIGN.md section 9)
     // wide maps (3x896x1600: level 3 is 112 x 200): 8 x 16 tiles with a frame - the flat run's patch (R + 2W + 2 rows)
     // no longer fits, and falling back to the slot kernel re-gathers every input 9 times
-    if (cfg(1)) ok = (t2 && try_launch<2, 2, 1, 2, 4, true, 2, true>(k, B, st)) || try_launch<2, 2, 1, 2, 6, true, 2>(k, B, st) ||
+    if (cfg(1)) ok = (one_round(2 * tiles8x16) && try_launch<1, 4, 1, 2, 4, true, 2, true, 1>(k, B, st)) ||   // (64 channels per workgroup)
+                     (t2 && try_launch<2, 2, 1, 2, 4, true, 2, true>(k, B, st)) || try_launch<2, 2, 1, 2, 6, true, 2>(k, B, st) ||
                      try_launch<2, 2, 1, 2, 4, true, 2, true>(k, B, st);   // (8 waves x 256 pixels measured 4 % slower here)
   } else {
     // 256+ channels: every 64-pixel tile streams the whole weight matrix from L2, which bounds these
@@ -572,7 +593,11 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
     const long tiles128 = (M + 127) / 128 * ((a->N_pad + 255) / 256);
     // smallest maps (level5, 14x25): 128 channels x 64 pixels per workgroup with K split over wave pairs
     // doubles the workgroup count and halves every wave's round chain (per-image rule, see above)
-    if ((long)a->H * a->W <= 512 && cfg(2)) ok = try_launch<2, 1, 2, 2, 4, true, 2>(k, B, st);
+    const long runs32 = (M + 31) / 32;
+    if ((long)a->H * a->W <= 512 && cfg(2))
+      ok = (one_round(runs32 * ((a->N_pad + 127) / 128)) && try_launch<2, 1, 2, 2, 4, true, 2, false, 1>(k, B, st)) ||
+           try_launch<2, 1, 2, 2, 4, true, 2>(k, B, st);
+    if (!ok && cfg(1) && one_round(runs32 * ((a->N_pad + 255) / 256))) ok = try_launch<4, 1, 1, 2, 4, true, 2, false, 1>(k, B, st);
     // (the tiled forms behind the flat ones: maps wider than ~60 / ~95 pixels, e.g. level 4 of a 3x896x1600 input)
     if (!ok && cfg(1)) ok = (tiles128 >= 160 && (try_launch<4, 2, 1, 2, 2, true, 1>(k, B, st) || try_launch<4, 2, 1, 2, 2, true, 1, true>(k, B, st))) ||
                             try_launch<4, 1, 1, 2, 4, true, 2>(k, B, st) || try_launch<4, 1, 1, 2, 2, true, 2, true>(k, B, st);
