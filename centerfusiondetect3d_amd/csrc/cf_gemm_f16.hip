@@ -806,7 +806,15 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   static const int direct_epi = [] { const char* e = getenv("CF_DCN_EPI"); return e ? atoi(e) == 0 : 0; }();
   k.direct_epilogue = direct_epi;
   const bool coal = (a->N & 3) == 0 && !k.direct_epilogue;   // whole-row epilogue through LDS
-  if (a->N_pad <= 64) {          // 64 channels: 2 x 32-channel wave rows, 2 x 64 pixels
+  // SMALL GRIDS (small batches): 64 output channels on 64-pixel tiles (the 128-channel configuration with two of its
+  // four channel-group waves idle in the MFMAs, all four staging) while that launch still fits the chip in one round:
+  // 128 -> 64 at 56x100, bs=1: 30.4 vs 43.4 us, bs=2: 31.6 vs 45.0 us; at 350 workgroups the gain is gone.  Same K order,
+  // same K split: bit-identical, so the choice may depend on the batch size (as in cf_conv3x3_f16x3).
+  if (a->N_pad <= 64 && (M + 63) / 64 * (long)ks <= 256) {
+    const dim3 grid((unsigned)((M + 63) / 64), 1u, ks);
+    if (coal) launch_f16(dcn_f16x3_kernel<4, 1, 1, true>, grid, 0, st, k);
+    else launch_f16(dcn_f16x3_kernel<4, 1, 1, false>, grid, 0, st, k);
+  } else if (a->N_pad <= 64) {          // 64 channels: 2 x 32-channel wave rows, 2 x 64 pixels
     const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((a->N_pad + 63) / 64), ks);
     if (coal) launch_f16(dcn_f16x3_kernel<2, 2, 1, true>, grid, 0, st, k);
     else launch_f16(dcn_f16x3_kernel<2, 2, 1, false>, grid, 0, st, k);
