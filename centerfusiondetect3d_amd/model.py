@@ -935,9 +935,21 @@ class DLASeg(nn.Module):
             gcal = calib.clone() if calib is not None else None
             graph = torch.cuda.CUDAGraph()
             plans = {}                                                 # owned by the graph (see _plan)
-            with torch.cuda.graph(graph):
-                cap_sid = torch.cuda.current_stream(dev).cuda_stream   # plans of the capture stream (own buffers)
-                gout = self._forward_eager(gx, gpc, gcal, B, H, W, dev, cap_sid, store=plans)[0]
+            # No garbage collection may run inside the capture: a collected object with device-side teardown (an older
+            # captured graph of a model that is itself garbage, say) aborts the process when its destructor runs while a
+            # stream is capturing - and torch.cuda.graph() no longer collects on entry by default.  Collect now, then hold
+            # the collector off until the capture has ended.
+            import gc
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(graph):
+                    cap_sid = torch.cuda.current_stream(dev).cuda_stream   # plans of the capture stream (own buffers)
+                    gout = self._forward_eager(gx, gpc, gcal, B, H, W, dev, cap_sid, store=plans)[0]
+            finally:
+                if gc_was_on:
+                    gc.enable()
             g = (graph, gx, gpc, gcal, gout, plans)
         self._graphs[key] = g                                          # most recently used last
         while len(self._graphs) > max(1, int(self.max_plan_sets)):

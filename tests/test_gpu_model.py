@@ -570,3 +570,31 @@ def test_plan_cache_is_an_lru_and_frees_evicted_buffers(dev):
             assert torch.equal(g["heatmap"], first[B]), B
             assert len(m._graphs) <= 4
         assert torch.equal(m(xd[:1], pc_dep=pd[:1], calib=cdv[:1])[0]["heatmap"], first[1])   # evicted graph re-captured
+
+
+def test_graph_capture_survives_pending_garbage_with_device_teardown(dev):
+    """A model that owns a captured graph and has become cyclic garbage must not be collected INSIDE another model's
+    capture (its graph's destructor would run while a stream is capturing and abort the process - seen once in the full
+    suite): _forward_graph collects first and holds the collector off during the capture.  Provoked here with a
+    collection threshold of 1."""
+    import gc
+    H, W = 96, 128
+    x, _, calib = cases.model_inputs(1, H, W, seed=3, radar=False)
+    xd, cdv = x.to(dev), calib.to(dev)
+    old = gc.get_threshold()
+    try:
+        with torch.no_grad():
+            a = _model(False, dev, (H, W))
+            a.use_graph = True
+            ref = a(xd, calib=cdv)[0]["heatmap"].clone()
+            cyc = [a]
+            cyc.append(cyc)                      # the first model is now reachable only through a cycle
+            del a, cyc
+            b = _model(False, dev, (H, W))
+            b.use_graph = True
+            gc.set_threshold(1, 1, 1)            # any allocation may trigger a full collection
+            got = b(xd, calib=cdv)[0]["heatmap"]
+        assert torch.equal(got, ref)
+    finally:
+        gc.set_threshold(*old)
+        gc.collect()
