@@ -573,10 +573,12 @@ def test_plan_cache_is_an_lru_and_frees_evicted_buffers(dev):
 
 
 def test_graph_capture_survives_pending_garbage_with_device_teardown(dev):
-    """A model that owns a captured graph and has become cyclic garbage must not be collected INSIDE another model's
-    capture (its graph's destructor would run while a stream is capturing and abort the process - seen once in the full
-    suite): _forward_graph collects first and holds the collector off during the capture.  Provoked here with a
-    collection threshold of 1."""
+    """The full GPU suite once died with `Fatal Python error: Aborted` while Python was GARBAGE-COLLECTING inside a graph
+    capture (plan building under torch.cuda.graph): some destructor with device-side teardown ran while a stream was
+    capturing (torch.cuda.graph() no longer collects on entry by default).  _forward_graph therefore collects first and
+    holds the collector off until the capture has ended.  This test drives that path with pending cyclic garbage that
+    owns a captured graph and a collection threshold of 1; it is a guard for the path, not a reproducer - in isolation the
+    abort did not show without the fix either."""
     import gc
     H, W = 96, 128
     x, _, calib = cases.model_inputs(1, H, W, seed=3, radar=False)
