@@ -304,6 +304,13 @@ def test_config_c2_full_size_properties(dev):
             part = m(xd[lo:hi].contiguous(), pc_dep=pd[lo:hi].contiguous(), calib=cd[lo:hi].contiguous())
             det, _ = decode_packed(part, (112, 200), 100)
             assert torch.equal(det, det_full[lo:hi])
+        # shards of 1 / 2 / 4 frames take the small-grid tiles (half-height 3x3 tiles, 64-pixel DCN tiles: the tile
+        # shape follows the launch size, the K order does not) - every output map bit for bit, not only the decode
+        ref_maps = m(xd, pc_dep=pd, calib=cd)
+        for lo, hi in ((5, 6), (6, 8), (12, 16)):
+            part = m(xd[lo:hi].contiguous(), pc_dep=pd[lo:hi].contiguous(), calib=cd[lo:hi].contiguous())
+            for k, v in part[0].items():
+                assert torch.equal(v, ref_maps[0][k][lo:hi]), (k, lo, hi)
     assert int((full[0]["pc_hm"] != 0).sum()) > 0
     # ... and frames of the bs=16 batch against the oracle (not only against the HIP path itself); `full` had
     # rotation2 renamed to rotation by the decode above, as the reference's decode does
