@@ -879,7 +879,8 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   // workgroups in flight work on the same few heads and their first-layer weights stay hot in L2, while the patch
   // is read from HBM once per range instead of once per head.
   const int hg = blockIdx.x / per_head;
-  int rem = blockIdx.x - hg * per_head;
+  // within a head range consecutive tiles run on ONE XCD: neighbouring patches share their halo rows in that XCD's L2
+  int rem = cf_xcd_remap(blockIdx.x - hg * per_head, per_head);
   const int head0 = hg * q.hloop, head1 = min(head0 + q.hloop, p.n_heads);
   const int b = rem / per_img;
   rem -= b * per_img;
