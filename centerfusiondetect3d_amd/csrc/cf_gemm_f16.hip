@@ -385,6 +385,14 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     for (int i = 0; i < WP; ++i) {
       const int pr = tid + 256 * i;
       const float mk = cmk[i];   // the mask (x 2^4 activation scale) is applied after the 4-corner sum, as the reference does
+#ifdef CF_DCN_NOBLEND       // (dev timing experiment: no blend / split arithmetic, the first corner's bits are staged as they are)
+      {
+        unsigned char* o = buf + (pr >> 2) * FROWB + (pr & 3) * 16;
+        *reinterpret_cast<f32x4*>(o) = cv[i][0][0] * mk;
+        *reinterpret_cast<f32x4*>(o + PLANE) = cv[i][0][1];
+        continue;
+      }
+#endif
       // explicit vector FMAs (v_pk_fma_f32: two channels per instruction)
       f32x4 v0 = cw[i][0] * cv[i][0][0], v1 = cw[i][0] * cv[i][0][1];
 #pragma unroll
@@ -548,7 +556,9 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
       store_b(nxt, cv, cw, cmk);
       if (j + 1 + NSET < n_own) load_b(c + 1 + NSET, cv, cw, cmk);
     }
+#ifndef CF_DCN_NOBARRIER   // (dev timing experiment: what the per-chunk workgroup barrier costs; results are garbage)
     __syncthreads();
+#endif
   };
   if (DEEP) {
     for (int j = 0; j < n_own; j += 2) {
