@@ -579,31 +579,47 @@ def test_plan_cache_is_an_lru_and_frees_evicted_buffers(dev):
         assert torch.equal(m(xd[:1], pc_dep=pd[:1], calib=cdv[:1])[0]["heatmap"], first[1])   # evicted graph re-captured
 
 
-def test_graph_capture_survives_pending_garbage_with_device_teardown(dev):
-    """The full GPU suite once died with `Fatal Python error: Aborted` while Python was GARBAGE-COLLECTING inside a graph
-    capture (plan building under torch.cuda.graph): some destructor with device-side teardown ran while a stream was
-    capturing (torch.cuda.graph() no longer collects on entry by default).  _forward_graph therefore collects first and
-    holds the collector off until the capture has ended.  This test drives that path with pending cyclic garbage that
-    owns a captured graph and a collection threshold of 1; it is a guard for the path, not a reproducer - in isolation the
-    abort did not show without the fix either."""
-    import gc
+def test_no_captured_graph_is_collected_inside_a_capture(dev):
+    """Collecting a torch.cuda.CUDAGraph that has become cyclic garbage while ANOTHER stream capture is under way aborts
+    the process (its destructor destroys the graph while the runtime is in global capture mode; plain-torch reproducer:
+    tools/repro_gc_capture.py graph -> rc 134, tensors / events survive).  That killed one full GPU suite run: the
+    models of earlier tests are cyclic garbage, and torch.cuda.graph() no longer collects on entry by default.
+    _forward_graph therefore (1) collects BEFORE the capture and (2) holds the collector off until it has ended - both
+    checked here from inside the capture: the dead model's graph is already gone, and the collector is disabled."""
+    import gc, weakref
     H, W = 96, 128
     x, _, calib = cases.model_inputs(1, H, W, seed=3, radar=False)
     xd, cdv = x.to(dev), calib.to(dev)
-    old = gc.get_threshold()
+    gc.collect()
+    was_on = gc.isenabled()
+    gc.disable()                                 # nothing is collected behind this test's back
+    seen = {}
     try:
         with torch.no_grad():
             a = _model(False, dev, (H, W))
             a.use_graph = True
             ref = a(xd, calib=cdv)[0]["heatmap"].clone()
+            dead_graph = weakref.ref(next(iter(a._graphs.values()))[0])
             cyc = [a]
             cyc.append(cyc)                      # the first model is now reachable only through a cycle
             del a, cyc
+            assert dead_graph() is not None      # ... and, with the collector off, still pending
             b = _model(False, dev, (H, W))
             b.use_graph = True
-            gc.set_threshold(1, 1, 1)            # any allocation may trigger a full collection
+            eager = b._forward_eager
+
+            def spy(*args, **kw):
+                if torch.cuda.is_current_stream_capturing():
+                    seen["graph_alive"] = dead_graph() is not None
+                    seen["gc_enabled"] = gc.isenabled()
+                return eager(*args, **kw)
+
+            b._forward_eager = spy
             got = b(xd, calib=cdv)[0]["heatmap"]
+        assert seen == {"graph_alive": False, "gc_enabled": False}, seen
         assert torch.equal(got, ref)
+        assert not gc.isenabled()                # _forward_graph restores the state it found (off, here)
     finally:
-        gc.set_threshold(*old)
+        if was_on:
+            gc.enable()
         gc.collect()
