@@ -154,6 +154,7 @@ def _param_spec(config) -> List[tuple]:
 _SIDE_STREAMS = {}    # (device, caller stream id) -> probed side streams, LRU of _SIDE_KEYS keys per PROCESS
 _SIDE_KEYS = 16
 _SIDE_LOCK = threading.Lock()
+_CAPTURE_LOCK = threading.RLock()   # held while a stream captures AND while a captured graph is destroyed (see _forward_graph)
 _PROBE_US = 300       # length of one probe spin; two of them take ~1x this when concurrent, ~2x when serialised
 _PROBE_LOG = []       # [(device, sid, n, chosen indices, [(i, j, ms)])]: what the probes measured (tests / DESIGN)
 
@@ -716,7 +717,8 @@ class DLASeg(nn.Module):
         self._packed = None
         self._plans = {}
         self._plan_sets = {}
-        self._graphs = {}
+        with _CAPTURE_LOCK:                  # (graphs are never destroyed while another thread's stream is capturing)
+            self._graphs = {}
 
     def _plan(self, key, build, store=None):
         """The plan under `key`, built on first use.  Plans of the eager path live in `self._plans` under an LRU of
@@ -940,20 +942,22 @@ class DLASeg(nn.Module):
             # stream is capturing - and torch.cuda.graph() no longer collects on entry by default.  Collect now, then hold
             # the collector off until the capture has ended.
             import gc
-            gc.collect()
-            gc_was_on = gc.isenabled()
-            gc.disable()
-            try:
-                with torch.cuda.graph(graph):
-                    cap_sid = torch.cuda.current_stream(dev).cuda_stream   # plans of the capture stream (own buffers)
-                    gout = self._forward_eager(gx, gpc, gcal, B, H, W, dev, cap_sid, store=plans)[0]
-            finally:
-                if gc_was_on:
-                    gc.enable()
+            with _CAPTURE_LOCK:
+                gc.collect()
+                gc_was_on = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(graph):
+                        cap_sid = torch.cuda.current_stream(dev).cuda_stream   # plans of the capture stream (own buffers)
+                        gout = self._forward_eager(gx, gpc, gcal, B, H, W, dev, cap_sid, store=plans)[0]
+                finally:
+                    if gc_was_on:
+                        gc.enable()
             g = (graph, gx, gpc, gcal, gout, plans)
         self._graphs[key] = g                                          # most recently used last
         while len(self._graphs) > max(1, int(self.max_plan_sets)):
-            self._graphs.pop(next(iter(self._graphs)))
+            with _CAPTURE_LOCK:
+                self._graphs.pop(next(iter(self._graphs)))
         graph, gx, gpc, gcal, gout, _plans = g
         gx.copy_(x)
         if gpc is not None:
