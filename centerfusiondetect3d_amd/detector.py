@@ -74,9 +74,12 @@ class Detector(object):
 
     # ---------------------------------------------------------------------------------- process
     @torch.no_grad()
-    def process(self, images, calibs, pc_dep=None, meta=None):
-        """forward + decode + postProcess -> (outputs, post (B,K,54))."""
+    def process(self, images, calibs, pc_dep=None, meta=None, mark=None):
+        """forward + decode + postProcess -> (outputs, post (B,K,54)).  `mark(name)`: stage-boundary callback (`run` with
+        `stage_times`)."""
         outputs = self.model(images, pc_dep=pc_dep, calib=calibs)
+        if mark is not None:
+            mark("net")
         outH, outW = self.config.MODEL.OUTPUT_SIZE
         key = (float(meta["center"][0]), float(meta["center"][1]), float(meta["scale"]), outH, outW)
         tinv = self._tinv.get(key)
@@ -163,13 +166,46 @@ class Detector(object):
                 pending = (outputs, post, metas, infos)
             yield self._finish(*pending, merge)
 
-    def run(self, imgInput, img_info=None, radar_pc=None, merge=True):
+    def run(self, imgInput, img_info=None, radar_pc=None, merge=True, stage_times=False):
         """imgInput: (H,W,3) uint8 ndarray, a list of them, or a (B,H,W,3) uint8 tensor; img_info: dict or list of
         dicts (`calib`, and for radar `camera_intrinsic`, `width`, `height`); radar_pc: (R,N) array or list.
         -> {"outputs", "post" (B,K,54) device, "metas", "img_infos" (the batch's own, as a list), "detects" (dict of host
-        tensors), "predictBoxes"}."""
+        tensors), "predictBoxes"}.
+
+        `stage_times=True` adds the reference's per-stage seconds under the reference's keys (its `@return_time` tracing
+        hook, utils/utils.py:52-66 on detector.py:44-470; `ret["load"] ... ret["display"]`, detector.py:140-155) plus
+        "tot".  The reference brackets every stage with two device synchronisations; here the device stages are
+        bracketed by HIP events on the caller's stream and read back once at the end, so timing a run does not
+        serialise host and device: "preprocess" (frame copy + warp + radar ingest + pillars), "net" (forward),
+        "decode" (the fused decode + postProcess launch), "postprocess" 0.0 (inside "decode"), "merge" (host: fetch +
+        box lists), "load" / "display" 0.0 (no file loading, no visualisation on this path)."""
         imgInput, img_info, radar_pc = self._as_batch(imgInput, img_info, radar_pc)
+        marks, mark = [], None
         with torch.cuda.device(self.device):
+            if stage_times:
+                stream = torch.cuda.current_stream(self.device)
+
+                def mark(name):
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(stream)
+                    marks.append((name, ev))
+
+                import time
+                t_host = time.perf_counter()
+                mark("start")
             images, pc_dep, metas, calibs = self.pre_process(imgInput, img_info, radar_pc)
-            outputs, post = self.process(images, calibs, pc_dep, metas[0])
-        return self._finish(outputs, post, metas, img_info, merge)
+            if stage_times:
+                mark("preprocess")
+            outputs, post = self.process(images, calibs, pc_dep, metas[0], mark)
+            if stage_times:
+                mark("decode")
+        if not stage_times:
+            return self._finish(outputs, post, metas, img_info, merge)
+        marks[-1][1].synchronize()
+        t_merge = time.perf_counter()
+        ret = self._finish(outputs, post, metas, img_info, merge)
+        t_end = time.perf_counter()
+        ret.update({"load": 0.0, "postprocess": 0.0, "display": 0.0, "merge": t_end - t_merge, "tot": t_end - t_host})
+        for (_, e0), (name, e1) in zip(marks[:-1], marks[1:]):
+            ret[name] = e0.elapsed_time(e1) * 1e-3
+        return ret

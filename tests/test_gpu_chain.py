@@ -323,3 +323,30 @@ def test_run_pipelined_equals_run(dev):
         assert list(det.run_pipelined(iter([]))) == []
         one = list(det.run_pipelined(iter(batches[:1]), merge=False))
         assert len(one) == 1 and torch.equal(one[0]["post"], ref[0]["post"])
+
+
+def test_run_stage_times_carry_the_reference_keys(dev):
+    """Detector.run(stage_times=True): the per-stage seconds of the reference's `@return_time` hook under the reference's own
+    keys (detector.py:140-155), measured with HIP events - same results as an untimed run, stages positive and adding up to
+    no more than the total."""
+    from centerfusiondetect3d_amd import Detector, centerfusion_middle_config
+    H, W = 128, 160
+    det = Detector(centerfusion_middle_config((H, W)), device=dev)
+    det.model.load_state_dict(cases.tuned_state_dict(radar=True, seed=0), strict=True)
+    calib = np.concatenate([cd.NUSC_K, np.zeros((3, 1))], axis=1)
+    B = 2
+    frames = torch.from_numpy(np.random.RandomState(7).randint(0, 256, (B, 900, 1600, 3)).astype(np.uint8))
+    infos = [dict(calib=calib.tolist(), camera_intrinsic=cd.NUSC_K.tolist(), width=1600, height=900)] * B
+    sweeps = [cd._sweep(np.random.RandomState(70 + b), 80) for b in range(B)]
+    with torch.no_grad():
+        plain = det.run(frames, infos, sweeps)
+        det.run(frames, infos, sweeps, stage_times=True)                  # (plans exist, clocks up)
+        timed = det.run(frames, infos, sweeps, stage_times=True)
+    assert torch.equal(plain["post"], timed["post"])
+    assert not any(k in plain for k in ("net", "tot"))
+    for k in ("load", "preprocess", "net", "decode", "postprocess", "merge", "display", "tot"):
+        assert isinstance(timed[k], float) and timed[k] >= 0.0, k
+    for k in ("preprocess", "net", "decode", "merge"):
+        assert 0.0 < timed[k] < 5.0, (k, timed[k])
+    assert timed["preprocess"] + timed["net"] + timed["decode"] <= timed["tot"] * 1.05
+    assert timed["load"] == timed["display"] == timed["postprocess"] == 0.0
