@@ -23,6 +23,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (this pool's driver only does dmabuf IPC: RCCL needs it; set before HIP starts)
+
 import numpy as np
 import torch
 
