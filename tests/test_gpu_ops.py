@@ -817,3 +817,45 @@ def test_radar_to_pc_dep_matches_the_oracle_chain(dev):
         _, _, dm = pillar_ref.process_point_cloud(r2, r3, calib, trans, out_hw)
         assert np.array_equal(got[b].cpu().numpy(), dm), f"frame {b}"
     assert int((got != 0).sum()) > 0
+
+
+def test_shards_reproduce_the_batch_bit_for_bit_at_random_shapes(dev):
+    """The tile shape of the 3x3 patch kernel and of the DCN kernel follows the launch size (half-height / 64-pixel tiles while
+    the grid fits one round); the K order never does.  So every frame alone and every pair of frames must equal its slice of
+    the full-batch result bit for bit - checked on 24 seeded random (B, H, W, Cin, Cout) around the dispatch
+    thresholds (tools/sweep_shard_bits.py ran 480 such cases: none differed), with the full batch against float64."""
+    from centerfusiondetect3d_amd import ops, packing
+    rs = np.random.RandomState(11)
+    done = 0
+    while done < 24:
+        B = int(rs.choice([2, 3, 4, 6]))
+        H = int(rs.choice([7, 14, 28, 56, int(rs.randint(5, 90))]))
+        W = int(rs.choice([13, 25, 50, 100, 200, int(rs.randint(5, 210))]))
+        Ci, Co = int(rs.choice([32, 64, 128, 256])), int(rs.choice([27, 64, 128, 256]))
+        if B * H * W * max(Ci, Co) > 6.0e7:
+            continue
+        done += 1
+        x, w, b = F.relu(rnd(B, Ci, H, W, seed=done)) * 3, rnd(Co, Ci, 3, 3, seed=100 + done, scale=(Ci * 9) ** -0.5), rnd(Co, seed=200 + done)
+        pc = packing.pack_conv_f16(w, b, [packing.Source(Ci, Ci)]).to(dev)
+        so = 32 if Co == 27 else Co
+        xd = nhwc(x).to(dev)
+        full = torch.zeros((B, H, W, so), device=dev)
+        ops.conv2d_f16x3(pc, [xd], B, H, W, act=1, out=full, patch=True)
+        ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1))
+        tag = f"B={B} {Ci}->{Co} {H}x{W}"
+        assert float((nchw(full[..., :Co]).cpu().double() - ref).abs().max() / ref.abs().max()) < 1.5e-6, tag
+        shards = [(i, i + 1) for i in range(B)] + [(i, i + 2) for i in range(0, B - 1, 2)]
+        for lo, hi in shards:
+            part = torch.zeros((hi - lo, H, W, so), device=dev)
+            ops.conv2d_f16x3(pc, [xd[lo:hi].contiguous()], hi - lo, H, W, act=1, out=part, patch=True)
+            assert torch.equal(part[..., :Co], full[lo:hi, ..., :Co]), (tag, lo, hi)
+        if Co != 27:
+            om = torch.zeros(B, H, W, 32)
+            om[..., :18] = rnd(B, H, W, 18, seed=300 + done) * 2.0
+            om[..., 18:27] = rnd(B, H, W, 9, seed=400 + done)
+            om = om.to(dev)
+            pd = packing.pack_dcn_f16(w, b).to(dev)
+            fulld = ops.dcn_v2_fused(pd, xd, om)
+            for lo, hi in shards:
+                partd = ops.dcn_v2_fused(pd, xd[lo:hi].contiguous(), om[lo:hi].contiguous())
+                assert torch.equal(partd, fulld[lo:hi]), ("dcn", tag, lo, hi)

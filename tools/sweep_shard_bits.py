@@ -1,0 +1,59 @@
+"""Dev (GPU box): randomised check of the rule behind SURVEY 8(e) - a shard of a batch reproduces the full batch BIT FOR BIT -
+on the two kernel families whose tile shape follows the launch size (conv3x3 LDS-patch kernel: half-height tiles while the
+grid fits one round; DCN: 64-pixel tiles for 64-output layers).  Random (B, H, W, Cin, Cout) around the dispatch thresholds;
+every frame alone and every pair must equal its slice of the full-batch result, and the full batch must agree with float64.
+    python tools/sweep_shard_bits.py [n_cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.nn.functional as F
+from centerfusiondetect3d_amd import ops, packing
+
+dev = torch.device("cuda:0")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+bad = 0
+for case in range(n_cases):
+    B = int(rs.choice([1, 2, 3, 4, 6, 8]))
+    H = int(rs.choice([7, 14, 28, 56, 112, int(rs.randint(5, 120))]))
+    W = int(rs.choice([13, 25, 50, 100, 200, int(rs.randint(5, 210))]))
+    Ci = int(rs.choice([32, 64, 128, 256]))
+    Co = int(rs.choice([27, 64, 128, 256]))
+    if B * H * W * max(Ci, Co) > 3.0e8:
+        continue
+    g = torch.Generator().manual_seed(case)
+    x = F.relu(torch.randn(B, Ci, H, W, generator=g)) * 3
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * (Ci * 9) ** -0.5
+    b = torch.randn(Co, generator=g)
+    # ---- conv3x3 (patch kernel where the map fits, the slot kernel otherwise: the dispatcher's choice either way)
+    pc = packing.pack_conv_f16(w, b, [packing.Source(Ci, Ci)]).to(dev)
+    so = 32 if Co == 27 else Co
+    xd = nhwc(x).to(dev)
+    full = torch.zeros((B, H, W, so), device=dev)
+    ops.conv2d_f16x3(pc, [xd], B, H, W, act=1, out=full, patch=True)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1))
+    err = float((full[..., :Co].permute(0, 3, 1, 2).cpu().double() - ref).abs().max() / ref.abs().max())
+    ok = err < 1.5e-6
+    for lo, hi in [(i, i + 1) for i in range(B)] + [(i, i + 2) for i in range(0, B - 1, 2)]:
+        part = torch.zeros((hi - lo, H, W, so), device=dev)
+        ops.conv2d_f16x3(pc, [xd[lo:hi].contiguous()], hi - lo, H, W, act=1, out=part, patch=True)
+        ok &= bool(torch.equal(part[..., :Co], full[lo:hi, ..., :Co]))
+    # ---- DCN (Cout padded to 32s by the packer)
+    ok_d = True
+    if Co != 27:
+        om = torch.zeros(B, H, W, 32)
+        om[..., :18] = torch.randn(B, H, W, 18, generator=g) * 2.0
+        om[..., 18:27] = torch.randn(B, H, W, 9, generator=g)
+        om = om.to(dev)
+        pd = packing.pack_dcn_f16(w, b).to(dev)
+        fulld = ops.dcn_v2_fused(pd, xd, om)
+        for lo, hi in [(i, i + 1) for i in range(B)] + [(i, i + 2) for i in range(0, B - 1, 2)]:
+            partd = ops.dcn_v2_fused(pd, xd[lo:hi].contiguous(), om[lo:hi].contiguous())
+            ok_d &= bool(torch.equal(partd, fulld[lo:hi]))
+    print(f"case {case:3d}: B={B} {Ci}->{Co} {H}x{W}: conv err {err:.1e} {'ok' if ok else 'MISMATCH'}; dcn {'ok' if ok_d else 'MISMATCH'}",
+          flush=True)
+    bad += (not ok) + (not ok_d)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)
