@@ -1,6 +1,6 @@
 """Dev tool (GPU box): A/B of the PRECISE (two-level) accumulation - accuracy vs fp64 and step time."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import model_ref
 from tests.golden import cases

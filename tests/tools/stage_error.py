@@ -1,9 +1,9 @@
 """Dev tool (GPU box): per-stage normwise error of the HIP path against the fp64 oracle, next to the
 CPU fp32 oracle's own error against fp64 - shows where fp32 rounding is amplified (the DCN neck).
-    gpurun -- python tools/stage_error.py
+    gpurun -- python tests/tools/stage_error.py
 """
 import torch, numpy as np, sys
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import model_ref
 from tests.golden import cases
 from centerfusiondetect3d_amd import getModel, centerfusion_middle_config
