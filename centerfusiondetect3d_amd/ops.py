@@ -222,6 +222,7 @@ def nchw_to_nhwc(x, out=None, out_offset=0):
 
 _DCN_PACKS = {}       # id(weight) -> (weakref to weight, weight version, weakref to bias or None, bias version, PackedDcn)
 _DCN_PACK_KEYS = 64   # LRU bound
+_DCN_PACK_LOCK = __import__("threading").Lock()   # (the operator may be called from several host threads)
 
 
 def _packed_dcn(weight, bias):
@@ -231,6 +232,11 @@ def _packed_dcn(weight, bias):
     can be reused by another tensor after the first one is freed."""
     import weakref
     from . import packing
+    with _DCN_PACK_LOCK:
+        return _packed_dcn_locked(weight, bias, weakref, packing)
+
+
+def _packed_dcn_locked(weight, bias, weakref, packing):
     key = id(weight)
     e = _DCN_PACKS.pop(key, None)
     if e is not None:
