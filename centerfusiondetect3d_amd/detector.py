@@ -11,11 +11,14 @@ path, end to end on the device:
 Only the raw bytes (frames, sweeps, calibration) cross PCIe; nothing is warped, projected, sorted,
 decoded or unprojected on the host.  Visualisation, file loading by path (cv2.imread) and the debug
 windows of the reference are outside the hot path."""
+import os
+
 import numpy as np
 import torch
 
 from . import _lib
 from .decode import decode_post_packed
+from .checkpoint import loadModel
 from .model import getModel
 from .pointcloud import getAffineTransform, radar_to_pc_dep
 from .postprocess import inverse_affine, unpack_post
@@ -25,13 +28,35 @@ FOCAL_LENGTH = 1200          # datasets/nuscenes.py:34 (used when an image has n
 
 
 class Detector(object):
-    def __init__(self, config, model=None, device=None):
+    def __init__(self, config, show=False, pause=False, *, model=None, device=None):
+        """detector.py:21-42: `Detector(config, show=False, pause=False)` builds the model with `getModel(config)`
+        and, when `config.MODEL.LOAD_DIR` is set (the reference's radar configs set it,
+        configs/Centerfusion_Middle.yaml:43), loads that checkpoint with `loadModel` before `.to(device).eval()`.
+        A checkpoint that cannot be read raises, as `torch.load` does in the reference: nothing here falls back to
+        random weights.  `model=` / `device=` (keyword only, extensions) hand over an already-built module or pick the
+        card.  Visualisation is outside the hot path: `show=True` raises instead of being ignored."""
+        if not isinstance(show, bool) or not isinstance(pause, bool):
+            raise TypeError("Detector(config, show=False, pause=False, *, model=None, device=None): "
+                            "show / pause are booleans; pass a pre-built module as model=")
+        if show:
+            raise NotImplementedError("Detector(show=True): the reference's debug windows (detector.py:115-187) are "
+                                      "outside the HIP hot path")
+        if model is None and config.MODEL.LOAD_DIR != "" and not os.path.isfile(config.MODEL.LOAD_DIR):
+            raise FileNotFoundError(f"config.MODEL.LOAD_DIR = {config.MODEL.LOAD_DIR!r}: no such checkpoint "
+                                    "(detector.py:30-31 loads it; it is never replaced by random weights)")
         if not torch.cuda.is_available():
             raise _lib.CfHipError("Detector runs on the GPU: the HIP path has no CPU fallback")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.config = config
-        self.model = (model if model is not None else getModel(config)).to(self.device).eval()
+        if model is None:
+            model = getModel(config)
+            if config.MODEL.LOAD_DIR != "":
+                _, model, _ = loadModel(model, config)
+        self.model = model.to(self.device).eval()
         self.mean, self.std = NUSCENES_MEAN, NUSCENES_STD
+        self.pause = pause
+        self.show = show
+        self.visualization = show
         self._tinv = {}
 
     # ------------------------------------------------------------------------------ pre_process

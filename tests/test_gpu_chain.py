@@ -325,6 +325,40 @@ def test_run_pipelined_equals_run(dev):
         assert len(one) == 1 and torch.equal(one[0]["post"], ref[0]["post"])
 
 
+def test_detector_loads_the_configured_checkpoint(dev, tmp_path):
+    """detector.py:28-33: `Detector(config)` with `MODEL.LOAD_DIR` set (configs/Centerfusion_Middle.yaml:43) runs the
+    CHECKPOINT's weights - here a DataParallel-prefixed file under the original CenterFusion release's parameter names
+    (tests/golden/legacy_keys.npz, from the reference's toggleWeightName) - bit for bit what a module filled by
+    load_state_dict gives; and not what a random-init module gives."""
+    from centerfusiondetect3d_amd import Detector, centerfusion_middle_config, getModel
+    H, W = 128, 160
+    g = np.load(os.path.join(GOLDEN, "legacy_keys.npz"))
+    new, old = list(g["centerfusion_new"]), list(g["centerfusion_old"])
+    sd = cases.tuned_state_dict(radar=True, seed=0)
+    assert list(sd.keys()) == new
+    path = tmp_path / "centerfusion_e60.pth"
+    torch.save({"epoch": 60, "state_dict": {"module." + o: sd[k] for k, o in zip(new, old)}}, path)
+    cfg = centerfusion_middle_config((H, W))
+    cfg.MODEL.LOAD_DIR = str(path)
+    det = Detector(cfg)                                              # the reference's call, nothing else
+    assert next(det.model.parameters()).device.type == "cuda" and not det.model.training
+    model = getModel(centerfusion_middle_config((H, W)))
+    model.load_state_dict(sd, strict=True)
+    det_ref = Detector(centerfusion_middle_config((H, W)), model=model, device=dev)
+    det_rand = Detector(centerfusion_middle_config((H, W)), device=dev)
+    calib = np.concatenate([cd.NUSC_K, np.zeros((3, 1))], axis=1)
+    B = 2
+    frames = torch.from_numpy(np.random.RandomState(11).randint(0, 256, (B, 900, 1600, 3)).astype(np.uint8))
+    infos = [dict(calib=calib.tolist(), camera_intrinsic=cd.NUSC_K.tolist(), width=1600, height=900)] * B
+    sweeps = [cd._sweep(np.random.RandomState(110 + b), 90) for b in range(B)]
+    with torch.no_grad():
+        got, ref, rnd = (d.run(frames, infos, sweeps, merge=False) for d in (det, det_ref, det_rand))
+    assert torch.equal(got["post"], ref["post"])
+    for k in ref["outputs"][0]:
+        assert torch.equal(got["outputs"][0][k], ref["outputs"][0][k]), k
+    assert not torch.equal(got["post"], rnd["post"])
+
+
 def test_run_stage_times_carry_the_reference_keys(dev):
     """Detector.run(stage_times=True): the per-stage seconds of the reference's `@return_time` hook under the reference's own
     keys (detector.py:140-155), measured with HIP events - same results as an untimed run, stages positive and adding up to

@@ -176,6 +176,28 @@ def test_legacy_keyed_checkpoint_loads(tmp_path):
             assert torch.equal(v, src[k]), k
 
 
+def test_detector_constructor_is_the_references(tmp_path):
+    """detector.py:21: `Detector(config, show=False, pause=False)`; our extensions (`model=`, `device=`) are keyword
+    only, so a positional `show` can never be taken for a module.  A `MODEL.LOAD_DIR` that names no file raises (the
+    reference's `torch.load` would, detector.py:30-31) - before anything touches the GPU, and never silently running
+    random-init weights; `show=True` (visualisation, out of scope) raises rather than being ignored."""
+    import inspect
+    from centerfusiondetect3d_amd import Detector
+    ps = list(inspect.signature(Detector.__init__).parameters.values())
+    assert [(p.name, p.default) for p in ps[:4]] == [("self", inspect.Parameter.empty),
+                                                      ("config", inspect.Parameter.empty), ("show", False), ("pause", False)]
+    assert all(p.kind is inspect.Parameter.KEYWORD_ONLY for p in ps[4:]) and {p.name for p in ps[4:]} == {"model", "device"}
+    cfg = centerfusion_middle_config((64, 64))
+    cfg.MODEL.LOAD_DIR = str(tmp_path / "no_such_checkpoint.pth")
+    with pytest.raises(FileNotFoundError):
+        Detector(cfg)
+    cfg.MODEL.LOAD_DIR = ""
+    with pytest.raises(NotImplementedError):
+        Detector(cfg, True)
+    with pytest.raises(TypeError):
+        Detector(cfg, getModel(cfg))                                   # the round-3 signature's positional model
+
+
 def test_reference_loader_accepts_our_module():
     """Where the reference is present (the build container): its own elasticLoadStateDict drives OUR module."""
     import os, sys
