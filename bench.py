@@ -40,8 +40,17 @@ DOMINANT = ["tails.primary", "tails.secondary"]
 # HBM-side bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes over this same command (FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md §HBM); bench.py cannot
 # run the profiler on itself, so the committed measurement is reported.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_pmc_hbm_traffic.json")
-C5_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_c5_pmc_hbm_traffic.json")
+def _latest(pattern):
+    """newest committed round of a profile file (profiles/rN_<pattern>)"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_" + pattern)),
+               key=lambda f: int(os.path.basename(f)[1:].split("_")[0]))
+    c = [f for f in c if os.path.basename(f).split("_", 1)[1] == pattern]
+    return c[-1] if c else os.path.join(ROOT, "profiles", "r3_" + pattern)
+
+
+TRAFFIC_FILE = _latest("pmc_hbm_traffic.json")
+C5_TRAFFIC_FILE = _latest("c5_pmc_hbm_traffic.json")
 LAYER_BYTES_PER_FRAME = 1.54e9    # SURVEY.md §8(d): layer-boundary traffic per 448x800 frame (every conv-like layer reads its
                                   # input once, writes its output once, reads its weights once, fp32)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
@@ -187,13 +196,18 @@ def cpu_baseline(H, W, batch=16, runs=3, seed=0):
                 ts.append(time.perf_counter() - t0)
         med = float(np.median(ts))
         return {"config": "C2 Centerfusion_Middle" if radar else "C1 CenterNet", "batch": bs, "runs": n_runs,
-                "median_s": round(med, 3), "frames_per_s": round(bs / med, 4)}
+                "median_s": round(med, 3), "min_s": round(min(ts), 3), "max_s": round(max(ts), 3),
+                "frames_per_s": round(bs / med, 4),
+                "frames_per_s_min_med_max": [round(bs / max(ts), 4), round(bs / med, 4), round(bs / min(ts), 4)]}
 
     legs = [leg(True, 1, runs), leg(True, batch, 1), leg(False, 1, runs)]
     total = sum(l["median_s"] * l["runs"] for l in legs)
     best = max(legs[:2], key=lambda l: l["frames_per_s"])
     return {"value": best["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
             "cpu": cpu_model_name(),
+            "spread": {"frames_per_s_min_med_max": best["frames_per_s_min_med_max"], "runs": best["runs"],
+                       "note": "this leg moved 2.2-3.3 frames/s between driver boxes of the same CPU model (rounds 2-3): "
+                               "context for the GPU figure, not a target"},
             "sample": f"torch-fp32 oracle forward+decode, 3x{H}x{W}: C2 bs=1 x{runs}, C2 bs={batch} x1, C1 bs=1 x{runs} "
                       f"after a 1-frame warm-up each, ~{total:.0f} s of CPU work; value = C2 at bs={best['batch']} "
                       f"(its faster batch size on this host)",
@@ -226,21 +240,39 @@ def end_to_end(args, dev, model):
             post = step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # resident-input floor of the same step (inputs already pre-processed on the device): the pipelined chain cannot
+        # beat it
+        images, pc_dep, metas, calibs = det.pre_process(frames, infos, sweeps)
+        for _ in range(2):
+            det.process(images, calibs, pc_dep, metas[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            det.process(images, calibs, pc_dep, metas[0])
+        torch.cuda.synchronize()
+        dt_r = time.perf_counter() - t0
         # the same batches through Detector.run_pipelined: batch i+1's PCIe copy + pre-processing on a feed stream
-        # beside batch i's forward (what the reference's DataLoader workers + pinned memory give it)
-        batches = ((frames, infos, sweeps) for _ in range(args.warmup + args.steps))
+        # beside batch i's forward (what the reference's DataLoader workers + pinned memory give it).  The generator
+        # yields batch i-1 after batch i's forward and batch i+1's staging are queued, so `warmup + steps + 2` batches
+        # are fed and the clock stops after `steps` yields: the timed region then holds exactly `steps` forwards
+        # (batches warmup+1 .. warmup+steps) and `steps` stagings (warmup+2 .. warmup+steps+1) - the work it is credited
+        batches = ((frames, infos, sweeps) for _ in range(args.warmup + args.steps + 2))
         gen = det.run_pipelined(batches, merge=False)
         for _ in range(args.warmup):
             next(gen)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for ret in gen:
-            post_p = ret["post"]
+        for _ in range(args.steps):
+            post_p = next(gen)["post"]
         torch.cuda.synchronize()
         dt_p = time.perf_counter() - t0
+        gen.close()
+        torch.cuda.synchronize()
     assert torch.equal(post_p, post)
     assert post.shape == (B, 100, 54) and bool(torch.isfinite(post).all())
+    assert dt_p >= 0.97 * dt_r, (dt_p, dt_r)            # (a pipelined chain faster than its own resident-input step is a timing bug)
     pipelined = {"frames_per_s": round(B * args.steps / dt_p, 2), "ms_per_step": round(dt_p / args.steps * 1e3, 3),
+                 "resident_ms_per_step": round(dt_r / args.steps * 1e3, 3),
                  "what": "Detector.run_pipelined: PCIe copy + pre-processing of batch i+1 on a feed stream beside batch i's forward"}
     return {"pipelined": pipelined, "metric": "frames/sec/GPU CenterFusion end-to-end: uint8 1600x900 frames + raw radar sweeps in pinned host "
                       "memory -> PCIe -> pre-process + radar ingest + pillar expansion -> forward -> decode + postProcess "
@@ -258,22 +290,46 @@ def other_configs(dev, steps=12):
     from centerfusiondetect3d_amd.postprocess import inverse_affine_device
     out = {}
 
-    def measure(B, H, W, offset_std):
-        model = synthetic_weights(getModel(centerfusion_middle_config((H, W))), seed=0, offset_std=offset_std).to(dev).eval()
+    def measure(B, H, W, offset_std, exact_fp32=False, steps=steps, warm=6):
+        model = getModel(centerfusion_middle_config((H, W)))
+        if exact_fp32:
+            model.conv_f16 = False
+            model.heads_bf16 = False
+        model = synthetic_weights(model, seed=0, offset_std=offset_std).to(dev).eval()
         images, pc_dep, calib = make_inputs(B, H, W, dev, seed=2000)
         tinv = inverse_affine_device(np.array([800.0, 450.0], np.float32), 1600.0, (W // 4, H // 4), dev)
+        dominant = ["heads.primary.0", "heads.secondary.0"] if exact_fp32 else []
         with torch.no_grad():
-            for _ in range(6):
+            for _ in range(warm):
                 decode_post_packed(model(images, pc_dep=pc_dep, calib=calib), calib, tinv, (H // 4, W // 4), 100)
+            for name in dominant:
+                model.time_launch(name, True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
                 decode_post_packed(model(images, pc_dep=pc_dep, calib=calib), calib, tinv, (H // 4, W // 4), 100)
             torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
+        r = {"ms_per_step": round(ms, 3), "frames_per_s": round(B / ms * 1e3, 1), "batch": B, "input": f"3x{H}x{W}"}
+        if exact_fp32:
+            l_ms, l_fl = [], 0.0
+            for name in dominant:
+                m_, f_ = model.launch_times(name)
+                l_ms += m_
+                l_fl += f_ * len(m_)
+            avg, fl = float(np.mean(l_ms)), l_fl / len(l_ms)
+            ach = fl / (avg * 1e-3) / 1e12
+            r["dtype"] = "f32"
+            r["model_tflops"] = round(B / ms * GFLOP_PER_FRAME * (H * W) / (448 * 800), 2)
+            r["model_frac_of_fp32_mfma_peak"] = round(r["model_tflops"] / FP32_MFMA_PEAK_TFLOPS, 4)
+            r["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                             "kernel": "conv_igemm_kernel (v_mfma_f32_32x32x2_f32; the 3x3 first layers of the 7 primary / "
+                                       "4 secondary heads)",
+                             "flop_per_launch": fl, "avg_launch_ms": round(avg, 4), "launches_timed": len(l_ms)}
         del model, images, pc_dep, calib
         torch.cuda.empty_cache()
-        return {"ms_per_step": round(ms, 3), "frames_per_s": round(B / ms * 1e3, 1), "batch": B, "input": f"3x{H}x{W}"}
+        return r
 
     out["C4_dcn_offsets_8px"] = measure(16, 448, 800, 0.04)
     c5 = out["C5_highres"] = measure(8, 896, 1600, 0.01)
@@ -282,15 +338,83 @@ def other_configs(dev, steps=12):
     # all kernels from the committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this configuration
     gbs = 4 * LAYER_BYTES_PER_FRAME * c5["frames_per_s"] / 1e9
     t5 = load_traffic(C5_TRAFFIC_FILE)
+    traffic5 = None if t5 is None else round(t5["_meta"]["hbm_bytes_per_forward_all_kernels"])
+    tflops5 = 4 * GFLOP_PER_FRAME * c5["frames_per_s"] / 1e3
     c5["roofline"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                      "frac": round(gbs / HBM_PEAK_GBS, 4),
-                      "traffic": None if t5 is None else round(t5["_meta"]["hbm_bytes_per_forward_all_kernels"]),
+                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic5,
                       "bytes_per_step": 4 * LAYER_BYTES_PER_FRAME * 8,
-                      "note": "whole step; algorithmic bytes = layer-boundary traffic (fp32 activations in/out + weights "
-                              "per conv-like layer); dominant kernels at 224x400 maps: see profiles/r3_c5_kernel_summary.txt"}
+                      # the HBM-side bytes the counters saw, over this run's step time: what the memory system really did
+                      "measured_gbs": None if traffic5 is None else round(traffic5 / c5["ms_per_step"] / 1e6, 1),
+                      "measured_frac": None if traffic5 is None else round(traffic5 / c5["ms_per_step"] / 1e6 / HBM_PEAK_GBS, 4),
+                      "mfma": {"achieved": round(tflops5, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tflops5 / BF16_MFMA_PEAK_TFLOPS, 4), "flop_per_step": 4 * GFLOP_PER_FRAME * 8e9},
+                      "note": "whole step.  `achieved` = ALGORITHMIC layer-boundary bytes (fp32 activations in/out + weights "
+                              "per conv-like layer) / time; the counters (`traffic`, `measured_gbs`) see half of that - "
+                              "fusion keeps the rest on chip - so the step is NOT HBM-bound at this size: like C2 it is "
+                              "bound by MFMA/VALU issue, and `mfma.frac` (x3 for pipe occupancy: 3 passes per MAC) is the "
+                              "figure the counters support.  Kernels at 224x400 maps: profiles/r4_c5_kernel_summary.txt"}
+    out["C2_exact_fp32"] = measure(16, 448, 800, 0.01, exact_fp32=True, steps=6, warm=2)
     out["C2_single_frame_latency"] = measure(1, 448, 800, 0.01)
     out["C2_one_nuscenes_sample_bs6"] = measure(6, 448, 800, 0.01)     # the 6 cameras of one sample (detector.py:44-155)
     return out
+
+
+class StepClock:
+    """Per-rank diagnostics of the timed steps, so that an N>1 line explains itself (8 Python launch threads share one
+    host; a bad scaling figure must be attributable to host enqueue, to the exchange, or to neither):
+      host_enqueue_ms  perf_counter around ONE step's launches - forward, decode + postProcess, all-gather submit -
+                       before any wait: the host-side cost of keeping the GPU fed;
+      gather_wait_ms   time the compute stream spends blocked on the previous step's all-gather (HIP events either side
+                       of `work.wait()`, which orders the stream and does not block the host); on CPU (gloo rehearsal) the
+                       host time of the blocking wait;
+      step_ms          this rank's own wall time per step (the headline uses the MAX over ranks).
+    Rank 0 prints every rank's figures as `ranks: [...]`."""
+    FIELDS = ("step_ms", "host_enqueue_ms", "gather_wait_ms", "gather_wait_host_ms")
+
+    def __init__(self, device):
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.on, self.enq, self.wait_host, self.wait_ev = False, [], [], []
+
+    def enqueue(self, fn):
+        t0 = time.perf_counter()
+        r = fn()
+        if self.on:
+            self.enq.append(time.perf_counter() - t0)
+        return r
+
+    def wait(self, pending):
+        if not self.on:
+            return pending.wait()
+        ev = None
+        if self.cuda and pending.work is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        t0 = time.perf_counter()
+        out = pending.wait()
+        self.wait_host.append(time.perf_counter() - t0)
+        if ev is not None:
+            ev[1].record()
+            self.wait_ev.append(ev)
+        return out
+
+    def row(self, dt, steps):
+        """-> [step_ms, host_enqueue_ms, gather_wait_ms, gather_wait_host_ms] of this rank (call after a device sync)."""
+        wh = 1e3 * float(np.mean(self.wait_host)) if self.wait_host else 0.0
+        wd = float(np.mean([a.elapsed_time(b) for a, b in self.wait_ev])) if self.wait_ev else (0.0 if self.cuda else wh)
+        return [dt / steps * 1e3, 1e3 * float(np.mean(self.enq)) if self.enq else 0.0, wd, wh]
+
+    @staticmethod
+    def gather_rows(row, world, device):
+        """every rank's row -> list of dicts on every rank (one small all-gather, outside the timed region)."""
+        import torch.distributed as dist
+        t = torch.tensor(row, dtype=torch.float64, device=device)
+        if world > 1:
+            out = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+        else:
+            out = [t]
+        return [dict(rank=r, **{k: round(float(v), 4) for k, v in zip(StepClock.FIELDS, o.tolist())})
+                for r, o in enumerate(out)]
 
 
 def free_port():
@@ -329,17 +453,21 @@ def rehearse(args, world, rank, collective, json_fd):
     B = args.batch
     gatherer = DetectionGatherer(torch.device("cpu"), force_collective=args.force_collective)
     pending, n_done = [], [0]
+    clock = StepClock(torch.device("cpu"))
 
-    def step():
+    def launches():
         post = torch.full((B, 100, 54), float(1000 * rank + n_done[0]))
         n_done[0] += 1
         pending.append(gatherer.submit(post))
-        return pending.pop(0).wait() if len(pending) > 1 else None
+
+    def step():
+        clock.enqueue(launches)
+        return clock.wait(pending.pop(0)) if len(pending) > 1 else None
 
     def drain():
         last = None
         while pending:
-            last = pending.pop(0).wait()
+            last = clock.wait(pending.pop(0))
         return last
 
     for _ in range(args.warmup):
@@ -347,6 +475,7 @@ def rehearse(args, world, rank, collective, json_fd):
     drain()
     if world > 1:
         dist.barrier()
+    clock.on = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -361,9 +490,10 @@ def rehearse(args, world, rank, collective, json_fd):
     t = torch.tensor([dt], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ranks = StepClock.gather_rows(clock.row(dt, args.steps), world if collective else 1, torch.device("cpu"))
     if rank == 0:
         os.write(json_fd, (json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world,
-                                       "steps": args.steps, "warmup": args.warmup, "rehearsal": True,
+                                       "steps": args.steps, "warmup": args.warmup, "rehearsal": True, "ranks": ranks,
                                        "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "scaling": "weak",
                                        "config": {"workload": "control-flow rehearsal on CPU (gloo), no forward",
                                                   "global_batch": B * world}}) + "\n").encode())
@@ -458,21 +588,25 @@ def main():
     tinv = inverse_affine_device(np.array([800.0, 450.0], np.float32), 1600.0, (W // 4, H // 4), dev)
     gatherer = DetectionGatherer(dev, force_collective=args.force_collective)
     pending = []
+    clock = StepClock(dev)
+
+    def launches():
+        out = model(images, pc_dep=pc_dep, calib=calib)
+        post = decode_post_packed(out, calib, tinv, (H // 4, W // 4), 100)
+        pending.append(gatherer.submit(post))
 
     def step():
         """forward -> decode + postProcess -> (N>1) async all-gather of the final boxes; the gather of step i is
         waited for after step i+1 has been enqueued, so it runs beside that step's backbone."""
-        out = model(images, pc_dep=pc_dep, calib=calib)
-        post = decode_post_packed(out, calib, tinv, (H // 4, W // 4), 100)
-        pending.append(gatherer.submit(post))
+        clock.enqueue(launches)
         if len(pending) > 1:
-            return pending.pop(0).wait()
+            return clock.wait(pending.pop(0))
         return None
 
     def drain():
         last = None
         while pending:
-            last = pending.pop(0).wait()
+            last = clock.wait(pending.pop(0))
         return last
 
     def fence():
@@ -490,12 +624,14 @@ def main():
         for name in dominant:
             model.time_launch(name, True)
         fence()
+        clock.on = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         det = drain()                      # every gather of the timed steps completes inside the timed region
         fence()
         dt = time.perf_counter() - t0
+        clock.on = False
     launch_ms, launch_flops = [], 0.0
     for name in dominant:
         ms, fl = model.launch_times(name)
@@ -507,6 +643,7 @@ def main():
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ranks = StepClock.gather_rows(clock.row(dt, args.steps), world, dev)   # (this rank's own dt, before the MAX)
     dt = float(t.item())
 
     if rank == 0:
@@ -527,6 +664,7 @@ def main():
                                    f"random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world} (batch shard, async all-gather of the final boxes)"},
             "per_gpu_frames_per_s": round(fps / world, 2),
+            "ranks": ranks,
             "model_tflops": round(fps * GFLOP_PER_FRAME * (H * W) / (448 * 800) / 1e3, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4),

@@ -25,6 +25,23 @@
 
 namespace {
 
+#ifdef CF_CONV3_SHAPE16T
+// (dev timing arm, results are garbage: every v_mfma_f32_32x32x16_f16 becomes two v_mfma_f32_16x16x32_f16 on quarters of
+//  the same accumulator - the same FLOPs, LDS reads, weight loads and registers, only the MFMA shape differs.  Costs the
+//  16x16x32 rewrite of this kernel before building it: DESIGN.md section 9.)
+__device__ __forceinline__ f32x16 mfma_shape16(f16x8 a, f16x8 b, f32x16 c) {
+  f32x4 q0 = {c[0], c[1], c[2], c[3]}, q1 = {c[8], c[9], c[10], c[11]};
+  q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q0, 0, 0, 0);
+  q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q1, 0, 0, 0);
+  c[0] = q0[0]; c[1] = q0[1]; c[2] = q0[2]; c[3] = q0[3];
+  c[8] = q1[0]; c[9] = q1[1]; c[10] = q1[2]; c[11] = q1[3];
+  return c;
+}
+#define CF_MFMA_F16(a, b, c) mfma_shape16(a, b, c)
+#else
+#define CF_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
+
 struct Conv3F {
   const float* x;               // fp32 NHWC, first channel of the source
   const unsigned char* weight;  // [N_pad/32][n_ks][2][64][8 f16]
@@ -233,23 +250,23 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #ifdef CF_ONESET   // (dev timing experiment: all three products into ONE accumulator set - fails the float64 RMS gate)
-          accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t % 3][rt], xh[t & 1][ct], accm[rt][ct], 0, 0, 0);
+          accm[rt][ct] = CF_MFMA_F16(wl[t % 3][rt], xh[t & 1][ct], accm[rt][ct]);
 #else
-          accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t % 3][rt], xh[t & 1][ct], accs[rt][ct], 0, 0, 0);
+          accs[rt][ct] = CF_MFMA_F16(wl[t % 3][rt], xh[t & 1][ct], accs[rt][ct]);
 #endif
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
-          accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t % 3][rt], xh[t & 1][ct], accm[rt][ct], 0, 0, 0);
+          accm[rt][ct] = CF_MFMA_F16(wh[t % 3][rt], xh[t & 1][ct], accm[rt][ct]);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #ifdef CF_ONESET
-          accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t % 3][rt], xl[ct], accm[rt][ct], 0, 0, 0);
+          accm[rt][ct] = CF_MFMA_F16(wh[t % 3][rt], xl[ct], accm[rt][ct]);
 #else
-          accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t % 3][rt], xl[ct], accs[rt][ct], 0, 0, 0);
+          accs[rt][ct] = CF_MFMA_F16(wh[t % 3][rt], xl[ct], accs[rt][ct]);
 #endif
       // tap t+3 of this round, or tap t-6 of the next one (same set either way)
       load_w(wh[t % 3], wl[t % 3], t + 3 < 9 ? ks0 + t + 3 : ks0 + 9 * WK + t - 6);

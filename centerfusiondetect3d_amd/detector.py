@@ -161,23 +161,32 @@ class Detector(object):
         should sit in pinned host memory for the copy to be asynchronous.  An extension: not in the reference's API."""
         from .model import _side_streams
         it = iter(batches)
+
+        def feed_stream(main):
+            # one stream past the model's own side streams, probed (model._pick_streams) to run beside them AND beside
+            # `main`, where the heads and the decode are
+            n = max(int(getattr(self.model, "streams", 2)), 2) + 1
+            return _side_streams(self.device, main.cuda_stream, n)[n - 1]
+
+        def stage(batch, feed):
+            imgInput, img_info, radar_pc = self._as_batch(*batch)
+            with torch.cuda.stream(feed):                           # (reads host memory only: no wait on `main`)
+                pre = self.pre_process(imgInput, img_info, radar_pc)
+                ev = torch.cuda.Event()
+                ev.record(feed)
+            return pre + (img_info,), ev
+
+        # The device context and the caller's stream are re-read on every resumption and never held across a `yield`:
+        # between two next() calls the caller's own device / stream context is untouched.
+        batch = next(it, None)
+        if batch is None:
+            return
         with torch.cuda.device(self.device):
-            main = torch.cuda.current_stream(self.device)
-            feed = _side_streams(self.device, main.cuda_stream, 3)[2]     # probed; not one of the model's own two
-
-            def stage(batch):
-                imgInput, img_info, radar_pc = self._as_batch(*batch)
-                with torch.cuda.stream(feed):                       # (reads host memory only: no wait on `main`)
-                    pre = self.pre_process(imgInput, img_info, radar_pc)
-                    ev = torch.cuda.Event()
-                    ev.record(feed)
-                return pre + (img_info,), ev
-
-            batch = next(it, None)
-            if batch is None:
-                return
-            staged, pending = stage(batch), None
-            while staged is not None:
+            staged = stage(batch, feed_stream(torch.cuda.current_stream(self.device)))
+        pending = None
+        while staged is not None:
+            with torch.cuda.device(self.device):
+                main = torch.cuda.current_stream(self.device)
                 (images, pc_dep, metas, calibs, infos), ev = staged
                 main.wait_event(ev)
                 for t in (images, pc_dep, calibs):
@@ -185,11 +194,15 @@ class Detector(object):
                         t.record_stream(main)                       # allocated on the feed stream, consumed on `main`
                 outputs, post = self.process(images, calibs, pc_dep, metas[0])       # batch i: queued on `main`
                 batch = next(it, None)
-                staged = stage(batch) if batch is not None else None                # batch i+1: beside it, on `feed`
-                if pending is not None:
-                    yield self._finish(*pending, merge)                              # batch i-1: host side
-                pending = (outputs, post, metas, infos)
-            yield self._finish(*pending, merge)
+                staged = stage(batch, feed_stream(main)) if batch is not None else None   # batch i+1: beside it
+                done, pending = pending, (outputs, post, metas, infos)
+                if done is not None:
+                    done = self._finish(*done, merge)                                # batch i-1: host side
+            if done is not None:
+                yield done
+        with torch.cuda.device(self.device):
+            last = self._finish(*pending, merge)
+        yield last
 
     def run(self, imgInput, img_info=None, radar_pc=None, merge=True, stage_times=False):
         """imgInput: (H,W,3) uint8 ndarray, a list of them, or a (B,H,W,3) uint8 tensor; img_info: dict or list of

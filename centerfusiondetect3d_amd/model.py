@@ -179,26 +179,28 @@ def _concurrent(lib, a, b, us=_PROBE_US):
 
 
 def _pick_streams(device, cur, n, pool):
-    """Extend `pool` to n streams that run concurrently with each other (and, for the first one, with the caller's
-    stream `cur`: the two-lane neck issues on `cur` and on pool[0]).  Candidates are taken from torch's stream pool
+    """Extend `pool` to n streams that run concurrently with each other and with the caller's stream `cur` (the
+    two-lane neck issues on `cur` and on pool[0]; the heads, the decode and `Detector.run_pipelined`'s consumer run on
+    `cur` beside whatever the last pool stream feeds).  Candidates are taken from torch's stream pool
     one at a time and kept only if a pair of spin kernels says they overlap with everything chosen so far - whatever
     else of the process (RCCL's communicator stream, other models, user streams) already sits on the hardware queues.
     Falls back to plain creation order if no concurrent set turns up within 12 candidates (still correct, only slower)."""
     lib = _lib.load()
-    torch.cuda.synchronize(device)
     tried, log = [], []
-    while len(pool) < n and len(tried) < 12:
-        c = torch.cuda.Stream(device)
-        tried.append(c)
-        ok = True
-        for x in ([cur] if not pool else []) + pool:
-            good, ms = _concurrent(lib, x, c)
-            log.append((len(tried) - 1, "caller" if x is cur else pool.index(x), round(ms, 3)))
-            if not good:
-                ok = False
-                break
-        if ok:
-            pool.append(c)
+    with _CAPTURE_LOCK:                       # the probe synchronises: never beside another thread's stream capture
+        torch.cuda.synchronize(device)
+        while len(pool) < n and len(tried) < 12:
+            c = torch.cuda.Stream(device)
+            tried.append(c)
+            ok = True
+            for x in [cur] + pool:
+                good, ms = _concurrent(lib, x, c)
+                log.append((len(tried) - 1, "caller" if x is cur else pool.index(x), round(ms, 3)))
+                if not good:
+                    ok = False
+                    break
+            if ok:
+                pool.append(c)
     fallback = len(pool) < n
     for c in tried:                           # not enough concurrent ones: take what was created, in order
         if len(pool) >= n:
@@ -217,8 +219,15 @@ def _side_streams(device, sid, n):
     at all (8.5 vs 10.5 ms per bs=16 step), and under torchrun RCCL has taken streams before the first model exists.
     During a graph capture nothing may synchronise: fresh streams are forked as they come (the replay's placement is
     the graph executor's, not these streams')."""
-    with _SIDE_LOCK:
-        key = (str(device), int(sid))
+    key = (str(device), int(sid))
+    with _SIDE_LOCK:                              # the common case: the set exists
+        pool = _SIDE_STREAMS.get(key)
+        if pool is not None and len(pool) >= n:
+            _SIDE_STREAMS[key] = _SIDE_STREAMS.pop(key)          # re-inserted last: dict order is the LRU order
+            return pool[:n]
+    # streams are missing: the probe synchronises the device, which must not happen beside another thread's stream
+    # capture - lock order is _CAPTURE_LOCK, then _SIDE_LOCK, everywhere (a capturing thread holds the first already)
+    with _CAPTURE_LOCK, _SIDE_LOCK:
         pool = _SIDE_STREAMS.pop(key, [])
         if len(pool) < n:
             if torch.cuda.is_current_stream_capturing():
@@ -226,7 +235,7 @@ def _side_streams(device, sid, n):
                     pool.append(torch.cuda.Stream(device))
             else:
                 pool = _pick_streams(device, torch.cuda.current_stream(device), n, pool)
-        _SIDE_STREAMS[key] = pool             # re-inserted last: dict order is the LRU order
+        _SIDE_STREAMS[key] = pool
         while len(_SIDE_STREAMS) > _SIDE_KEYS:
             _SIDE_STREAMS.pop(next(iter(_SIDE_STREAMS)))
         return pool[:n]

@@ -220,16 +220,51 @@ def nchw_to_nhwc(x, out=None, out_offset=0):
     return out
 
 
-_DCN_PACKS = {}       # id(weight) -> (weakref to weight, weight version, weakref to bias or None, bias version, PackedDcn)
+_DCN_PACKS = {}       # id(weight) -> (weakref to weight, weight stamp, weakref to bias or None, bias stamp, PackedDcn)
 _DCN_PACK_KEYS = 64   # LRU bound
 _DCN_PACK_LOCK = __import__("threading").Lock()   # (the operator may be called from several host threads)
+_DCN_PACK_VERIFY = True
+
+
+def set_dcn_pack_verify(on=True):
+    """`deform_conv2d` keeps the packed form of each weight it has seen.  An in-place write through `weight.data`
+    (`w.data.copy_()`, an EMA swap, a hand-written checkpoint load) bumps no version counter autograd can see, so with
+    verification ON (the default) every call also compares a 64-bit checksum of the live weight and bias bits with the one
+    taken when the entry was packed - one small reduction and one device->host scalar per call.  Turn it off for a serving
+    loop whose weights are frozen (and call `clear_dcn_pack_cache()` after any manual write).  -> previous setting."""
+    global _DCN_PACK_VERIFY
+    prev, _DCN_PACK_VERIFY = _DCN_PACK_VERIFY, bool(on)
+    return prev
+
+
+def clear_dcn_pack_cache():
+    """Drop every packed weight `deform_conv2d` holds (they are rebuilt on the next call)."""
+    with _DCN_PACK_LOCK:
+        _DCN_PACKS.clear()
+
+
+def _stamp(t):
+    """what autograd and the allocator can tell about a tensor's contents without reading them"""
+    return (t._version, t.data_ptr(), tuple(t.shape), t.dtype)
+
+
+def _checksum(weight, bias):
+    """64-bit sum of the raw bits (order-independent, exact: integer arithmetic) - a device scalar."""
+    def bits(t):
+        t = t.detach().contiguous()
+        return t.view(torch.int32 if t.element_size() == 4 else torch.int16 if t.element_size() == 2 else torch.int64)
+    c = bits(weight).sum(dtype=torch.int64)
+    if bias is not None:
+        c = c * 1000003 + bits(bias).sum(dtype=torch.int64)
+    return c
 
 
 def _packed_dcn(weight, bias):
-    """Pack (split fp16 hi / lo, MFMA fragment order: packing.pack_dcn_f16) ONCE per weight tensor OBJECT and version - the
-    reference calls the operator with the same nn.Parameter every forward (dla.py:464-465).  The entry holds weak
-    references and is valid only while they still point at the very tensors passed in: a data pointer or an id() alone
-    can be reused by another tensor after the first one is freed."""
+    """Pack (split fp16 hi / lo, MFMA fragment order: packing.pack_dcn_f16) ONCE per weight tensor OBJECT and content -
+    the reference calls the operator with the same nn.Parameter every forward (dla.py:464-465).  The entry holds weak
+    references and is valid only while they still point at the very tensors passed in (a data pointer or an id() alone
+    can be reused by another tensor after the first one is freed), their version counter, data pointer, shape and dtype
+    are unchanged, and - `set_dcn_pack_verify` - their bits still add up to the checksum taken at packing time."""
     import weakref
     from . import packing
     with _DCN_PACK_LOCK:
@@ -239,17 +274,27 @@ def _packed_dcn(weight, bias):
 def _packed_dcn_locked(weight, bias, weakref, packing):
     key = id(weight)
     e = _DCN_PACKS.pop(key, None)
+    verify = _DCN_PACK_VERIFY and weight.is_cuda and not torch.cuda.is_current_stream_capturing()
+    csum = None
     if e is not None:
-        wref, wver, bref, bver, pd = e
-        same_bias = (bref is None) if bias is None else (bref is not None and bref() is bias and bver == bias._version)
-        if not (wref() is weight and wver == weight._version and same_bias and pd.weight.device == weight.device):
+        wref, wst, bref, bst, pd, csum0 = e
+        same_bias = (bref is None) if bias is None else (bref is not None and bref() is bias and bst == _stamp(bias))
+        if not (wref() is weight and wst == _stamp(weight) and same_bias and pd.weight.device == weight.device):
             e = None
+        elif verify:
+            csum = int(_checksum(weight, bias).item())
+            if csum0 is None:
+                e = (wref, wst, bref, bst, pd, csum)      # packed during a capture: the checksum is taken now
+            elif csum != csum0:
+                e = None
     if e is None:
         w = weight.detach().float().cpu()
         b = torch.zeros(w.shape[0]) if bias is None else bias.detach().float().cpu()
         pd = packing.pack_dcn_f16(w, b).to(weight.device)
-        e = (weakref.ref(weight), weight._version, None if bias is None else weakref.ref(bias),
-             None if bias is None else bias._version, pd)
+        if verify and csum is None:
+            csum = int(_checksum(weight, bias).item())
+        e = (weakref.ref(weight), _stamp(weight), None if bias is None else weakref.ref(bias),
+             None if bias is None else _stamp(bias), pd, csum if verify else None)
     for k in [k for k, v in _DCN_PACKS.items() if v[0]() is None]:
         del _DCN_PACKS[k]                         # weights that no longer exist: free their packed copies now
     _DCN_PACKS[key] = e                           # re-inserted last: dict order is the LRU order

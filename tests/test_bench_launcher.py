@@ -47,6 +47,13 @@ def test_multi_rank_control_flow_rehearsal_bare_spawn():
     d = _one_json_line(p.stdout)
     assert d["rehearsal"] is True and d["value"] is None and d["n_gpus"] == 2 and d["config"]["global_batch"] == 32
     assert d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
+    # every rank's own diagnostics (bench.StepClock): step time, host time to enqueue one step, wait on the exchange
+    assert [r["rank"] for r in d["ranks"]] == [0, 1]
+    for r in d["ranks"]:
+        assert set(r) == {"rank", "step_ms", "host_enqueue_ms", "gather_wait_ms", "gather_wait_host_ms"}
+        assert r["step_ms"] > 0 and r["host_enqueue_ms"] > 0 and r["gather_wait_ms"] >= 0
+        assert r["host_enqueue_ms"] + r["gather_wait_host_ms"] <= r["step_ms"] * 1.5
+    assert d["ms_per_step"] >= max(r["step_ms"] for r in d["ranks"]) - 1e-3        # the headline is the MAX over ranks
 
 
 def test_multi_rank_control_flow_rehearsal_under_the_drivers_launch_line():
@@ -64,3 +71,4 @@ def test_multi_rank_control_flow_rehearsal_under_the_drivers_launch_line():
     assert p.returncode == 0, p.stderr[-2000:]
     d = _one_json_line(p.stdout)
     assert d["n_gpus"] == 3 and d["config"]["global_batch"] == 48 and d["rehearsal"] is True
+    assert [r["rank"] for r in d["ranks"]] == [0, 1, 2]

@@ -103,6 +103,41 @@ def test_weights_are_packed_once_per_version(dev):
         torch.testing.assert_close(got, _ref.deform_conv2d(x.cpu(), off.cpu(), wk, None, S, P, D, None), rtol=1e-4, atol=1e-4)
 
 
+def test_writes_through_dot_data_are_seen(dev):
+    """`w.data.copy_()` / `w.data.mul_()` / `w.data = ...` (an EMA swap, a hand-rolled checkpoint load) bump no version
+    counter of the Parameter: the packed-weight cache notices through the data pointer and the checksum of the live bits;
+    with verification off, `clear_dcn_pack_cache()` is the explicit way."""
+    from centerfusiondetect3d_amd import ops
+    x, off = rnd(1, 32, 9, 11, seed=1).to(dev), rnd(1, 18, 9, 11, seed=2).to(dev)
+    w = torch.nn.Parameter(rnd(32, 32, 3, 3, seed=3).to(dev))
+    bias = torch.nn.Parameter(rnd(32, seed=4).to(dev))
+    ops.clear_dcn_pack_cache()
+    a = ops.deform_conv2d(x, off, w, bias, S, P, D, None)
+    v0 = w._version
+    w.data.mul_(2.0)
+    bias.data.mul_(2.0)
+    assert w._version == v0                                  # (what makes this case invisible to a version check)
+    torch.testing.assert_close(ops.deform_conv2d(x, off, w, bias, S, P, D, None), 2 * a, rtol=1e-5, atol=1e-5)
+    w.data.copy_(w.data * 0.5)
+    bias.data.copy_(bias.data * 0.5)
+    torch.testing.assert_close(ops.deform_conv2d(x, off, w, bias, S, P, D, None), a, rtol=1e-5, atol=1e-5)
+    w.data = (w.data * 3.0).clone()                          # a new storage behind the same Parameter object
+    bias.data = (bias.data * 3.0).clone()
+    torch.testing.assert_close(ops.deform_conv2d(x, off, w, bias, S, P, D, None), 3 * a, rtol=1e-5, atol=1e-5)
+    assert len(ops._DCN_PACKS) == 1
+    prev = ops.set_dcn_pack_verify(False)
+    try:
+        assert prev is True
+        b3 = ops.deform_conv2d(x, off, w, bias, S, P, D, None)
+        w.data.mul_(2.0)
+        bias.data.mul_(2.0)
+        assert torch.equal(ops.deform_conv2d(x, off, w, bias, S, P, D, None), b3)     # frozen-weights mode: stale by contract
+        ops.clear_dcn_pack_cache()
+        torch.testing.assert_close(ops.deform_conv2d(x, off, w, bias, S, P, D, None), 6 * a, rtol=1e-5, atol=1e-5)
+    finally:
+        ops.set_dcn_pack_verify(True)
+
+
 # ---- the known-answer tests of tests/test_oracle_dcn.py, through the HIP kernel (Cin padded to the kernel's 32) ----
 def test_kat_zero_offset_unit_mask_is_conv2d(dev):
     x, w, b = rnd(2, 32, 13, 17), rnd(6, 32, 3, 3, seed=1, scale=1 / 17), rnd(6, seed=2)
