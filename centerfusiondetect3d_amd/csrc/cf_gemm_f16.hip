@@ -696,331 +696,6 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// WAVE-SPECIALISED form of the DCNv2 GEMM for the 64-output-channel layers (dla_up.ida_2.* / ida_up.*: 60 % of all
-// DCN time).  In dcn_f16x3_kernel every wave walks gather -> blend -> split -> stage -> barrier -> MFMA for each 32-deep
-// chunk, and the phases of a wave never overlap (MFMA pipe 16 % busy, 15 VALU per MFMA).  Here a
-// workgroup of 8 waves owns 256 pixels x 64 channels and splits the ROLES: waves 4-7 only gather (descriptors, corner
-// loads, blend, split, LDS stores), waves 0-3 only multiply (B fragments from LDS, weights from L2, MFMA, epilogue).
-// Wave w and wave w + 4 land on the same SIMD (tools/micro/wave_simd.hip), so every SIMD holds one gather wave and one
-// MFMA wave: the matrix pipe runs under the other wave's VALU / memory instructions instead of waiting for its own.
-//   * gather wave k stages exactly the 64 pixels MFMA wave k multiplies: the hand-off is pairwise, through a ring of
-//     NSLOT chunk buffers in LDS and two counters per pair (produced / consumed) - no workgroup barrier in the K loop.
-//     LDS executes one wave's operations in issue order, so "data stores, then the counter store" needs no fence; the
-//     consumer reads the counter, then the data.
-//   * sampling descriptors are built per tap (64 pixels per gather wave, one tap ahead) instead of for the whole tile:
-//     16 KB of LDS instead of 74.
-//   * same K order, same products and accumulator sets as dcn_f16x3_kernel<2,2,1>: bit-identical outputs.
-// ---------------------------------------------------------------------------------------------
-constexpr int WS_NSLOT = 3;                      // chunk buffers per (gather, MFMA) pair
-constexpr int WS_PLANE = 64 * FROWB;             // one plane (hi or lo) of one pair's chunk: 64 pixels x 80 B
-constexpr int WS_PAIRB = 2 * WS_PLANE;           // one pair's chunk buffer
-constexpr int WS_SLOTB = 4 * WS_PAIRB;           // one ring slot (4 pairs)
-constexpr int WS_DESCB = 64 * 32;                // one pair's descriptors of one tap
-constexpr int WS_LDS = WS_NSLOT * WS_SLOTB + 4 * 2 * WS_DESCB + 64;
-
-__device__ __forceinline__ int ws_flag_read(const int* f) {
-  int v;
-  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)f) : "memory");
-  return __builtin_amdgcn_readfirstlane(v);   // (every lane read the same word: the polling loop is scalar control flow)
-}
-// Counter store as a DS instruction by construction: a volatile store through a generic pointer compiles to flat_store
-// (+ vmcnt(0)), which does NOT stay in order with the wave's ds_write data stores - the hand-off relies on that order.
-__device__ __forceinline__ void ws_flag_write(int* f, int v) {
-  asm volatile("ds_write_b32 %0, %1" : : "v"((unsigned)(size_t)f), "v"(v) : "memory");
-}
-// Wait until *f >= need.  The protocol cannot deadlock (a gather wave blocks only when NSLOT chunks ahead, an MFMA wave
-// only on a chunk its gather wave has not finished, both counters only grow), so the bound is a safety net: a wave that
-// gives up after ~20 ms raises the workgroup's error word, and the MFMA waves then store NaN - wrong loudly, never a
-// hung queue.
-__device__ __forceinline__ void ws_wait(const int* f, int need, int* err) {
-#pragma unroll 1
-  for (int spin = 0; ws_flag_read(f) < need; ++spin) {
-    if (spin > (1 << 18)) {
-      ws_flag_write(err, 1);
-      return;
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-
-__global__ __launch_bounds__(512, 1) void dcn_ws_kernel(DcnF p) {
-  constexpr int RT = 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* ring = smem;
-  unsigned char* descs = smem + WS_NSLOT * WS_SLOTB;
-  int* flags = reinterpret_cast<int*>(smem + WS_NSLOT * WS_SLOTB + 4 * 2 * WS_DESCB);   // produced[4], consumed[4]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int k = wave & 3;                                  // the pair
-  const bool producer = wave >= 4;
-  const int m0 = cf_xcd_remap(blockIdx.x, gridDim.x) * 256 + 64 * k;   // first pixel of the pair
-  const int n_ks = p.n_chunks * 2;
-  const int HW = p.H * p.W;
-  if (tid < 9) flags[tid] = 0;
-  __syncthreads();
-  int* produced = flags + k;
-  int* consumed = flags + 4 + k;
-  int* err = flags + 8;
-  unsigned char* pair_ring = ring + k * WS_PAIRB;          // + slot * WS_SLOTB + plane * WS_PLANE + pixel * FROWB
-
-  if (producer) {
-    // ------------------------------------------------------------------------------ gather wave
-    f32x4* dsc = reinterpret_cast<f32x4*>(descs + k * 2 * WS_DESCB);   // [tap & 1][64 pixels][dA, dB]
-    const int mpx = min(m0 + lane, p.M - 1);               // descriptor role: lane = pixel of the pair
-    const bool px_ok = m0 + lane < p.M;
-    const float* omp = p.om + (size_t)mpx * p.om_stride;
-    const int pb = mpx / HW, prem = mpx - pb * HW;
-    const int pho = prem / p.W, pwo = prem - pho * p.W;
-    auto make_desc = [&](int tap, float oy, float ox, float om) {
-      f32x4 dA = {0.0f, 0.0f, 0.0f, 0.0f}, dB = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (px_ok) {
-        const int ti = tap / 3, tj = tap - ti * 3;
-        const float hf = (float)(pho - 1 + ti) + oy;
-        const float wf = (float)(pwo - 1 + tj) + ox;
-        const bool inside = hf > -1.0f && hf < (float)p.H && wf > -1.0f && wf < (float)p.W;
-        const float hfl = floorf(hf), wfl = floorf(wf);
-        const int hl = inside ? (int)hfl : 0, wl = inside ? (int)wfl : 0;
-        const float lh = hf - hfl, lw = wf - wfl, hh = 1.0f - lh, hw = 1.0f - lw;
-        const bool t_ok = inside && hl >= 0, b_ok = inside && hl + 1 <= p.H - 1;
-        const bool l_ok = wl >= 0, r_ok = wl + 1 <= p.W - 1;
-        const int y0 = max(hl, 0), x0 = max(wl, 0);
-        const int y1 = min(hl + 1, p.H - 1), x1 = min(wl + 1, p.W - 1);
-        dA[0] = __int_as_float(((pb * p.H + y0) * p.W + x0) * p.C);
-        dA[1] = __int_as_float((max(x1, x0) - x0) * p.C);
-        dA[2] = __int_as_float((max(y1, y0) - y0) * p.W * p.C);
-        dA[3] = (p.mask_activated ? om : cf_sigmoid(om)) * ASCALE;
-        dB[0] = (t_ok && l_ok) ? hh * hw : 0.0f;
-        dB[1] = (t_ok && r_ok) ? hh * lw : 0.0f;
-        dB[2] = (b_ok && l_ok) ? lh * hw : 0.0f;
-        dB[3] = (b_ok && r_ok) ? lh * lw : 0.0f;
-      }
-      f32x4* d = dsc + (tap & 1) * 128 + 2 * lane;
-      d[0] = dA;
-      d[1] = dB;
-    };
-    float oy = omp[0], ox = omp[1], om = omp[18];
-    make_desc(0, oy, ox, om);
-    oy = omp[2]; ox = omp[3]; om = omp[19];                // tap 1, used when tap 0 starts
-
-    // staging role: lane -> (pixel (lane >> 2) + 16 i, 8-channel unit lane & 3), i = 0..3; two pairs per stage, the corner
-    // loads of stage g + 1 are in flight while stage g is blended (16 dwordx4 loads per lane outstanding)
-    f32x4 cv[2][2][4][2];
-    f32x4 cw[2][2];
-    float cmk[2][2];
-    auto issue = [&](int c, int half, f32x4 (&v)[2][4][2], f32x4 (&w)[2], float (&mk)[2]) __attribute__((always_inline)) {
-      const int tap = c / p.chunks_per_tap;
-      const int c0 = (c - tap * p.chunks_per_tap) * 32 + (lane & 3) * 8;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int px = (lane >> 2) + 16 * (2 * half + j);
-        const f32x4* d = dsc + (tap & 1) * 128 + 2 * px;
-        const f32x4 dA = d[0];
-        w[j] = d[1];
-        mk[j] = dA[3];
-        const float* a0 = p.x + (__float_as_int(dA[0]) + c0);
-        const float* a1 = a0 + __float_as_int(dA[1]);
-        const float* a2 = a0 + __float_as_int(dA[2]);
-        const float* a3 = a2 + __float_as_int(dA[1]);
-        v[j][0][0] = *reinterpret_cast<const f32x4*>(a0);
-        v[j][0][1] = *reinterpret_cast<const f32x4*>(a0 + 4);
-        v[j][1][0] = *reinterpret_cast<const f32x4*>(a1);
-        v[j][1][1] = *reinterpret_cast<const f32x4*>(a1 + 4);
-        v[j][2][0] = *reinterpret_cast<const f32x4*>(a2);
-        v[j][2][1] = *reinterpret_cast<const f32x4*>(a2 + 4);
-        v[j][3][0] = *reinterpret_cast<const f32x4*>(a3);
-        v[j][3][1] = *reinterpret_cast<const f32x4*>(a3 + 4);
-      }
-    };
-    auto finish = [&](int c, int half, const f32x4 (&v)[2][4][2], const f32x4 (&w)[2], const float (&mk)[2]) __attribute__((always_inline)) {
-      unsigned char* buf = pair_ring + (c % WS_NSLOT) * WS_SLOTB;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int px = (lane >> 2) + 16 * (2 * half + j);
-        f32x4 v0 = w[j][0] * v[j][0][0], v1 = w[j][0] * v[j][0][1];
-#pragma unroll
-        for (int q = 1; q < 4; ++q) {
-          const f32x4 wq = {w[j][q], w[j][q], w[j][q], w[j][q]};
-          v0 = __builtin_elementwise_fma(wq, v[j][q][0], v0);
-          v1 = __builtin_elementwise_fma(wq, v[j][q][1], v1);
-        }
-        v0 *= mk[j];
-        v1 *= mk[j];
-        u32x4 hi, lo;
-        { unsigned th, tl; split2(v0[0], v0[1], th, tl); hi[0] = th; lo[0] = tl; }
-        { unsigned th, tl; split2(v0[2], v0[3], th, tl); hi[1] = th; lo[1] = tl; }
-        { unsigned th, tl; split2(v1[0], v1[1], th, tl); hi[2] = th; lo[2] = tl; }
-        { unsigned th, tl; split2(v1[2], v1[3], th, tl); hi[3] = th; lo[3] = tl; }
-        unsigned char* o = buf + px * FROWB + (lane & 3) * 16;
-        *reinterpret_cast<u32x4*>(o) = hi;
-        *reinterpret_cast<u32x4*>(o + WS_PLANE) = lo;
-      }
-      if (half == 1) {                                     // chunk complete: data stores, then the counter (LDS: issue order)
-        ws_flag_write(produced, c + 1);
-      }
-    };
-
-    // Per chunk: [the slot's previous chunk has been read] -> request stage (c, 1) -> blend / split / store stage (c, 0),
-    // requested a stage ago -> request stage (c + 1, 0) -> blend stage (c, 1).  No control flow between a request and the
-    // blend of the OLDER stage, so the wait in front of a blend is "all but the 16 youngest loads", not "all".
-    issue(0, 0, cv[0], cw[0], cmk[0]);
-    int c = 0;
-    for (int tap = 0; tap < 9; ++tap) {
-      if (tap + 1 < 9) {                                   // descriptors of the NEXT tap (its offsets were requested a tap
-        make_desc(tap + 1, oy, ox, om);                    // ago), offsets of the one after
-        const int t2 = min(tap + 2, 8);
-        oy = omp[2 * t2]; ox = omp[2 * t2 + 1]; om = omp[18 + t2];
-      }
-      for (int cb = 0; cb < p.chunks_per_tap; ++cb, ++c) {
-        ws_wait(consumed, c - WS_NSLOT + 1, err);
-        issue(c, 1, cv[1], cw[1], cmk[1]);
-        finish(c, 0, cv[0], cw[0], cmk[0]);
-        issue(min(c + 1, p.n_chunks - 1), 0, cv[0], cw[0], cmk[0]);   // (past the end: a redundant, valid request)
-        finish(c, 1, cv[1], cw[1], cmk[1]);
-      }
-    }
-    return;
-  }
-
-  // -------------------------------------------------------------------------------- MFMA wave
-  const int li = lane & 31, h = lane >> 5;
-  f32x16 accm[RT][2], accs[RT][2];
-#pragma unroll
-  for (int a = 0; a < RT; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        accm[a][b][r] = 0.0f;
-        accs[a][b][r] = 0.0f;
-      }
-  f16x8 wh[4][RT], wl[4][RT];           // weight fragments of k-steps ks .. ks + 3: requested three k-steps ahead
-  auto load_w = [&](f16x8 (&dh)[RT], f16x8 (&dl)[RT], int ks) {
-    ks = min(ks, n_ks - 1);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      dh[rt] = *wfrag16(p.weight, rt, ks, 0, n_ks, lane);
-      dl[rt] = *wfrag16(p.weight, rt, ks, 1, n_ks, lane);
-    }
-  };
-  f16x8 xh[2][2], xl[2][2];             // [k-step parity][column tile]
-  auto read_b = [&](int c, int s, f16x8 (&dh)[2], f16x8 (&dl)[2]) {
-    const unsigned char* buf = pair_ring + (c % WS_NSLOT) * WS_SLOTB;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const unsigned char* row = buf + (ct * 32 + li) * FROWB + s * 32 + h * 16;
-      dh[ct] = *reinterpret_cast<const f16x8*>(row);
-      dl[ct] = *reinterpret_cast<const f16x8*>(row + WS_PLANE);
-    }
-  };
-  // the same three products per (row tile, column tile) and k-step, into the same accumulator sets and in the same order
-  // PER ACCUMULATOR as dcn_f16x3_kernel::mma_kstep (accs: lo*hi then hi*lo; accm: hi*hi) - issued as three sweeps so that
-  // no MFMA waits on the one just before it
-  auto mma = [&](const f16x8 (&bh)[2], const f16x8 (&bl)[2], const f16x8 (&ah)[RT], const f16x8 (&al)[RT]) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rt], bh[ct], accs[rt][ct], 0, 0, 0);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rt], bh[ct], accm[rt][ct], 0, 0, 0);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rt], bl[ct], accs[rt][ct], 0, 0, 0);
-  };
-  // One chunk = two k-steps.  The B fragments of a k-step are requested one k-step ahead (LDS latency under 12 MFMAs), the
-  // `produced` counter is read a whole k-step before its value is needed, and the slot goes back to the gather wave as
-  // soon as the chunk's last fragment is in registers.  sched_barrier keeps the requests in front of the MFMAs.
-  auto chunk = [&](int c, f16x8 (&ah0)[RT], f16x8 (&al0)[RT], f16x8 (&ah1)[RT], f16x8 (&al1)[RT]) __attribute__((always_inline)) {
-    read_b(c, 1, xh[1], xl[1]);
-    int pv;                                                // early look at the next chunk: the read is in flight under the
-    asm volatile("ds_read_b32 %0, %1" : "=v"(pv) : "v"((unsigned)(size_t)produced) : "memory");   // MFMAs below; its value
-    __builtin_amdgcn_sched_barrier(0);                     // exists for the compiler only behind the s_waitcnt that follows
-    mma(xh[0], xl[0], ah0, al0);
-    load_w(ah0, al0, 2 * c + 4);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pv) : : "memory");   // every fragment of chunk c is in registers: hand the slot back
-    ws_flag_write(consumed, c + 1);
-    if (c + 1 < p.n_chunks) {
-      if (__builtin_amdgcn_readfirstlane(pv) < c + 2) ws_wait(produced, c + 2, err);
-      read_b(c + 1, 0, xh[0], xl[0]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mma(xh[1], xl[1], ah1, al1);
-    load_w(ah1, al1, 2 * c + 5);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-#pragma unroll
-  for (int i = 0; i < 4; ++i) load_w(wh[i], wl[i], i);
-  ws_wait(produced, 1, err);
-  read_b(0, 0, xh[0], xl[0]);
-  int c = 0;
-  for (; c + 1 < p.n_chunks; c += 2) {
-    chunk(c, wh[0], wl[0], wh[1], wl[1]);
-    chunk(c + 1, wh[2], wl[2], wh[3], wl[3]);
-  }
-  if (c < p.n_chunks) chunk(c, wh[0], wl[0], wh[1], wl[1]);   // (odd chunk count: 9 * C / 32 with C = 32, 96, ...)
-
-  // ---- epilogue: as dcn_f16x3_kernel's coalesced form; the transposition tile is the pair's slot-0 buffer (the pair's gather
-  // wave has stored its last chunk, and every fragment has been read)
-  {
-    constexpr int EROW = RT * 128 + 16;
-    constexpr int LPP = RT * 8, PPI = 64 / LPP;
-    static_assert(32 * EROW <= WS_PAIRB, "transposition tile fits the pair's chunk buffer");
-    asm volatile("; cf_epilogue_begin" ::: "memory");   // marker for tools/check_isa.py (no instruction)
-    unsigned char* eb = pair_ring;
-    const bool dead = ws_flag_read(err) != 0;
-    const int chunk = lane % LPP, psub = lane / LPP;
-    const int n = chunk * 4;
-    const bool n_ok = n < p.N;
-    f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (n_ok) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      cf_wave_lds_sync();                    // (first pass: the fragment reads; later: every lane has read the previous tile)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
-          *reinterpret_cast<f32x4*>(eb + li * EROW + (rt * 32 + 8 * g + 4 * h) * 4) = v;
-        }
-      cf_wave_lds_sync();                    // the tile is complete before any lane reads another lane's part
-#pragma unroll
-      for (int it = 0; it < 32 / PPI; ++it) {
-        const int ploc = it * PPI + psub;
-        const size_t m = (size_t)m0 + ct * 32 + ploc;
-        f32x4 v = *reinterpret_cast<const f32x4*>(eb + ploc * EROW + chunk * 16) + bias4;
-        if (n_ok && m < (size_t)p.M) {
-          if (p.act == CF_ACT_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-          }
-          if (dead) v = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-          *reinterpret_cast<f32x4*>(p.out + m * p.out_stride + n) = v;
-          if (p.out_split) {   // hi = rne_bf16(v), lo = rne_bf16(v - hi): the head kernels' input format
-            unsigned w[4];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              const __bf16 h0 = (__bf16)v[2 * e], h1 = (__bf16)v[2 * e + 1];
-              const __bf16 l0 = (__bf16)(v[2 * e] - (float)h0), l1 = (__bf16)(v[2 * e + 1] - (float)h1);
-              w[e] = ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16) | __builtin_bit_cast(unsigned short, h0);
-              w[2 + e] = ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16) | __builtin_bit_cast(unsigned short, l0);
-            }
-            unsigned* o = p.out_split + (m * 2 * p.split_stride + n) / 2;
-            *reinterpret_cast<uint2*>(o) = uint2{w[0], w[1]};
-            *reinterpret_cast<uint2*>(o + p.split_stride / 2) = uint2{w[2], w[3]};
-          }
-        }
-      }
-    }
-  }
-}
-
 // K-split reduction: out = act((sum_z partial[z]) * out_scale + bias), partials added in z order
 __global__ __launch_bounds__(256) void dcn_reduce_kernel(const float* __restrict__ partial, int ks, long MN4, int ns4,
                                                          int N, const float* __restrict__ bias, float out_scale,
@@ -1145,17 +820,6 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   // four channel-group waves idle in the MFMAs, all four staging) while that launch still fits the chip in one round:
   // 128 -> 64 at 56x100, bs=1: 30.4 vs 43.4 us, bs=2: 31.6 vs 45.0 us; at 350 workgroups the gain is gone.  Same K order,
   // same K split: bit-identical, so the choice may depend on the batch size (as in cf_conv3x3_f16x3).
-  // wave-specialised form (4 gather + 4 MFMA waves, 256 pixels): the 64-channel layers once the launch fills the chip
-  // (one workgroup per CU); bit-identical to the <2,2,1> tile below, so the choice may depend on the batch size.
-  // CF_DCN_WS=0: dev A/B.
-  static const int ws_on = [] { const char* e = getenv("CF_DCN_WS"); return e ? atoi(e) : 1; }();
-  static const long ws_min = [] { const char* e = getenv("CF_DCN_WS_MIN"); return e ? atol(e) : 200L; }();   // (dev: tiles)
-  if (ws_on && a->N_pad == 64 && coal && ks == 1 && (M + 255) / 256 >= ws_min) {
-    static CfLdsLimit ws_lds;
-    ws_lds.ensure(dcn_ws_kernel, (size_t)WS_LDS, (size_t)WS_LDS);
-    hipLaunchKernelGGL(dcn_ws_kernel, dim3((unsigned)((M + 255) / 256)), dim3(512), (size_t)WS_LDS, st, k);
-    return cf_check_launch("cf_dcn_v2_f16x3");
-  }
   if (a->N_pad <= 64 && (M + 63) / 64 * (long)ks <= 256) {
     const dim3 grid((unsigned)((M + 63) / 64), 1u, ks);
     if (coal) launch_f16(dcn_f16x3_kernel<4, 1, 1, true>, grid, 0, st, k);

@@ -694,39 +694,6 @@ def test_dcn_v2_f16x3(dev, B, Ci, Co, H, W, mag):
     assert torch.equal(out2, ops.dcn_v2_fused(pd, nhwc(x).to(dev), om32.to(dev), k_split=False))
 
 
-@pytest.mark.parametrize("B,Ci,Co,H,W,mag", [(4, 64, 64, 112, 200, 2.0), (3, 128, 64, 131, 137, 6.0), (7, 32, 60, 90, 100, 1.0)])
-def test_dcn_wave_specialised_form_equals_tile_form(dev, B, Ci, Co, H, W, mag):
-    """The 64-channel layers run the wave-specialised kernel (4 gather + 4 MFMA waves, 256-pixel tiles, pairwise LDS
-    ring hand-off) once the launch holds >= 200 such tiles; smaller launches run the <2,2,1> / <4,1,1> tile kernels.  Same
-    K order and accumulator sets: an image gives the same bits inside a large batch (specialised form) and alone (tile
-    form) - including the split-bf16 copy, ragged last tiles and pixels past M - and stays at fp32-level accuracy."""
-    from centerfusiondetect3d_amd import ops, packing
-    assert (B * H * W + 255) // 256 >= 200 > (H * W + 255) // 256
-    x = rnd(B, Ci, H, W, seed=1)
-    om = rnd(B, 27, H, W, seed=2)
-    om[:, :18] *= mag
-    w, b = rnd(Co, Ci, 3, 3, seed=3, scale=(Ci * 9) ** -0.5), rnd(Co, seed=4)
-    pd = packing.pack_dcn_f16(w, b).to(dev)
-    om32 = torch.zeros(B, H, W, 32)
-    om32[..., :27] = nhwc(om)
-    xd, omd = nhwc(x).to(dev), om32.to(dev)
-    cs = (Co + 7) // 8 * 8
-    split = torch.full((B, H, W, 2, cs), float("nan"), device=dev, dtype=torch.bfloat16)
-    out = torch.full((B, H, W, Co), float("nan"), device=dev)
-    ops.run_dcn(ops.dcn_args(pd, xd, omd, 32, B, H, W, out, Co, out_split=split))
-    for i in range(B):
-        split1 = torch.full((1, H, W, 2, cs), float("nan"), device=dev, dtype=torch.bfloat16)
-        out1 = torch.full((1, H, W, Co), float("nan"), device=dev)
-        ops.run_dcn(ops.dcn_args(pd, xd[i:i + 1].contiguous(), omd[i:i + 1].contiguous(), 32, 1, H, W, out1, Co, out_split=split1))
-        assert torch.equal(out[i:i + 1], out1), i
-        assert torch.equal(split[i:i + 1][..., :Co].view(torch.int16), split1[..., :Co].view(torch.int16)), i
-    o1, o2, m = torch.chunk(om[:1], 3, dim=1)
-    ref = F.relu(dcn_ref.deform_conv2d(x[:1].double(), torch.cat((o1, o2), 1).double(), w.double(), b.double(),
-                                       (1, 1), (1, 1), (1, 1), torch.sigmoid(m.double())))
-    err = float((nchw(out[:1]).cpu().double() - ref).abs().max() / ref.abs().max())
-    assert err < 5e-6, err
-
-
 def test_dcn_v2_f16x3_rejects_odd_tile_counts_above_128(dev):
     """N_pad = 160 would give the two-row-tiles-per-wave kernel a tile past the packed weights: refused, not run."""
     from centerfusiondetect3d_amd import ops, packing, _lib
