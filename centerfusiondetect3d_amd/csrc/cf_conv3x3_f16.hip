@@ -18,7 +18,13 @@
 // added in fixed wave order through LDS at the end).  WK > 1 is for small feature maps with many
 // input channels (the 14x25 / 28x50 offset convolutions), where pixel tiles alone cannot fill 256 CUs.
 //
-// Replaces the 3x3 stride-1 convolutions of model/networks/dla.py:42-62 (BasicBlock conv1/conv2) and
+// STRIDE 2 (S2, tiled form only; the four BasicBlock conv1 layers that open levels 2-5, dla.py:124-145): an output tile of
+// TH x 16 pixels needs the (2 TH + 1) x 33 input pixels around it.  The patch keeps each input row as two PLANES - the
+// 17 odd columns 2 (x0 + j) - 1, then the 16 even columns 2 (x0 + j) - so that tap (dy, dx) of output pixel (py, px) sits
+// at row 2 py + dy, entry {px, 17 + px, px + 1}[dx]: a compile-time offset per tap, exactly as in the stride-1 tile.  Every
+// input element is fetched and split ~1.1 times instead of the slot kernel's 2.25.
+//
+// Replaces the 3x3 convolutions of model/networks/dla.py:42-62, 124-145 (BasicBlock conv1/conv2) and
 // the conv_offset_mask of model/networks/dla.py:406-414 (DeformConv) on the device.
 #include <stdlib.h>
 #include "cf_f16x3.h"
@@ -48,8 +54,9 @@ struct Conv3F {
   const float* bias;
   const float* residual;
   float* out;
-  int x_stride, H, W, HW, M, N, n_rt, n_ks, n_rounds, res_stride, out_stride, act, PR;
+  int x_stride, H, W, HW, M, N, n_rt, n_ks, n_rounds, res_stride, out_stride, act, PR;   // H, W, HW, M: the OUTPUT map
   int tiles_x, tiles_y;         // T2 only
+  int Hi, Wi, HWi;              // S2 only: the input map (H, W are then the output's)
   float out_scale;
 };
 
@@ -60,12 +67,14 @@ struct Conv3F {
 // CT = 32-pixel column tiles per wave: 2 (64 x 64 wave tiles, two waves per SIMD at 256 registers each) or 4 - the
 // ONE-WAVE-PER-SIMD form (MINB = 1, 512 registers: both accumulator sets of a 64-channel x 128-pixel tile, 256 registers,
 // sit in AGPRs; every weight fragment is fetched once per 128 pixels instead of once per 64).
-template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2, int CT = 2>
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2, int CT = 2, bool S2 = false>
 __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
   constexpr int NT = 64 * WC * WP * WK;     // 4 waves, or 8 (WP doubled: two pixel groups share each weight fragment through L1)
   static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
+  static_assert(!S2 || (T2 && WK == 1), "stride 2: tiled form, no K split");
   constexpr int R = 32 * CT * WP;
-  constexpr int PW2 = 18;                   // T2: patch width (16 + 2)
+  constexpr int PW2 = S2 ? 33 : 18;         // T2: entries per patch row (16 + 2; stride 2: 17 odd + 16 even input columns)
+  constexpr int PYS = S2 ? 2 : 1;           // patch rows per output row
   constexpr int ROWB = 64 * WK + 16;        // per patch row: WK x (16 hi + 16 lo f16) + pad (odd multiple of 16 B)
   constexpr int UPR = 4 * WK;               // 16-byte fp32 units per patch row
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -94,6 +103,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     tx0 = (rem % p.tiles_x) * 16;
     m0 = b * p.HW;
   }
+  const int m0i = S2 ? (m0 / p.HW) * p.HWi : m0;   // first pixel of the image in the INPUT map
   const int rt0 = (blockIdx.y * WC + wc) * RT;
   const bool w_ok = rt0 < p.n_rt;
   const int bufb = (p.PR + 1) * ROWB;       // + the zero row
@@ -111,7 +121,12 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
   for (int it = 0; it < NU; ++it) {
     const int u = tid + NT * it;
     const int row = u / UPR, q = u % UPR;
-    if (T2) {
+    if (S2) {
+      const int e = row % PW2;
+      const int y = 2 * ty0 - 1 + row / PW2, x = e < 17 ? 2 * (tx0 + e) - 1 : 2 * (tx0 + e - 17);
+      const bool ok = row < p.PR && (unsigned)y < (unsigned)p.Hi && (unsigned)x < (unsigned)p.Wi;
+      goff[it] = ok ? (m0i + y * p.Wi + x) * p.x_stride + 4 * q : -1;
+    } else if (T2) {
       const int y = ty0 - 1 + row / PW2, x = tx0 - 1 + row % PW2;
       const bool ok = row < p.PR && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
       goff[it] = ok ? (m0 + y * p.W + x) * p.x_stride + 4 * q : -1;
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
   for (int ct = 0; ct < CT; ++ct) {
     const int pl = wp * (32 * CT) + ct * 32 + li;
     const int m = m0 + pl;
-    rowb[ct] = (T2 ? (pl >> 4) * PW2 + (pl & 15) : pl) * ROWB + wk * 64 + h * 16;
+    rowb[ct] = (T2 ? (pl >> 4) * (PYS * PW2) + (pl & 15) : pl) * ROWB + wk * 64 + h * 16;
     unsigned mk = 0;
     if (T2) {
       mk = 0x1ffu;                           // the frame is part of the patch
@@ -231,6 +246,8 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     // keeps the compiler from sinking those prefetches back down to their first use
     f16x8 xh[2][CT], xl[CT];
     auto x_addr = [&](int ct, int t, int toff) { return (T2 || ((vmask[ct] >> t) & 1u)) ? rowb[ct] + toff : zrow; };
+    // stride 2: entry {px, 17 + px, px + 1} of patch row 2 py + dy (compile-time per tap)
+    auto s2_off = [](int t) { return ((t / 3) * PW2 + (t % 3 == 0 ? 0 : t % 3 == 1 ? 17 : 1)) * ROWB; };
     int toff = 0;                            // ((t / 3) * W + t % 3) * ROWB, built incrementally
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) xh[0][ct] = *reinterpret_cast<const f16x8*>(cur + x_addr(ct, 0, 0));
@@ -238,7 +255,8 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) xl[ct] = *reinterpret_cast<const f16x8*>(cur + x_addr(ct, t, toff) + 32);
-      toff += (t % 3 == 2) ? ((T2 ? PW2 : p.W) - 2) * ROWB : ROWB;
+      if (S2) toff = s2_off(t + 1);
+      else toff += (t % 3 == 2) ? ((T2 ? PW2 : p.W) - 2) * ROWB : ROWB;
       if (t + 1 < 9) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -442,12 +460,12 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
 #endif
 }
 
-template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2 = false, int CT = 2>
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2 = false, int CT = 2, bool S2 = false>
 bool try_launch(Conv3F k, int batch, hipStream_t st) {
   constexpr int R = 32 * CT * WP, ROWB = 64 * WK + 16;
   long blocks;
   if (T2) {
-    k.PR = (R / 16 + 2) * 18;
+    k.PR = S2 ? (2 * (R / 16) + 1) * 33 : (R / 16 + 2) * 18;
     k.tiles_x = (k.W + 15) / 16;
     k.tiles_y = (k.H + R / 16 - 1) / (R / 16);
     blocks = (long)k.tiles_x * k.tiles_y * batch;
@@ -463,7 +481,8 @@ bool try_launch(Conv3F k, int batch, hipStream_t st) {
   constexpr size_t epi = (size_t)(64 * WC * WP * WK / 64) * 32 * (RT * 128 + 16);   // the waves' transposition tiles
   if (WK == 1 && NT == 256 && dyn < epi) dyn = epi;
   if (dyn > 160 * 1024) return false;
-  auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB, T2, CT>;
+  if (S2 && MINB >= 2 && dyn > 80 * 1024) return false;
+  auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB, T2, CT, S2>;
   static CfLdsLimit lds_limit;                // (one per template instantiation)
   lds_limit.ensure(kernel, dyn, 65536);
   const dim3 grid((unsigned)blocks, (unsigned)((k.n_rt + WC * RT - 1) / (WC * RT)));
@@ -483,7 +502,10 @@ bool tiles_fit(int H, int W) {
 extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
   CF_REQUIRE(a != nullptr, "cf_conv3x3_f16x3: null args");
   CF_REQUIRE(a->n_src == 1 && a->src[0] && a->src_c[0] > 0 && a->src_c[0] % 4 == 0, "cf_conv3x3_f16x3: one fp32 NHWC source");
-  CF_REQUIRE(a->stride == 1 && a->Ho == a->H && a->Wo == a->W, "cf_conv3x3_f16x3: stride 1, pad 1 only");
+  const bool s2 = a->stride == 2;
+  CF_REQUIRE((a->stride == 1 && a->Ho == a->H && a->Wo == a->W) ||
+             (s2 && a->Ho == (a->H - 1) / 2 + 1 && a->Wo == (a->W - 1) / 2 + 1), "cf_conv3x3_f16x3: 3x3, pad 1, stride 1 or 2");
+  CF_REQUIRE(!s2 || !a->residual, "cf_conv3x3_f16x3: no residual on the stride-2 form");
   CF_REQUIRE(a->K_pad > 0 && a->K_pad % 32 == 0, "cf_conv3x3_f16x3: K_pad=%d not a multiple of 32", a->K_pad);
   CF_REQUIRE(a->N > 0 && a->N_pad >= a->N && (a->N_pad == 32 || a->N_pad % 64 == 0), "cf_conv3x3_f16x3: N=%d N_pad=%d", a->N, a->N_pad);
   CF_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "cf_conv3x3_f16x3: bad geometry");
@@ -498,14 +520,15 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
   CF_REQUIRE(slices >= 1 && (a->K_pad == slices * 144 || a->K_pad == slices * 144 + 16),
              "cf_conv3x3_f16x3: K_pad=%d is not a slice-major 3x3 packing", a->K_pad);
   CF_REQUIRE(slices * 16 <= a->src_c[0], "cf_conv3x3_f16x3: %d input channels exceed the source width %d", slices * 16, a->src_c[0]);
-  const long M = (long)a->B * a->H * a->W;
-  CF_REQUIRE(M * a->src_c[0] < (1L << 31) && M < (1L << 31), "cf_conv3x3_f16x3: tensor too large");
+  const long M = (long)a->B * a->Ho * a->Wo;
+  CF_REQUIRE((long)a->B * a->H * a->W * a->src_c[0] < (1L << 31) && M < (1L << 31), "cf_conv3x3_f16x3: tensor too large");
   Conv3F k{};
   k.x = a->src[0];
   k.weight = reinterpret_cast<const unsigned char*>(a->weight);
   k.bias = a->bias; k.residual = a->residual; k.out = a->out;
   k.x_stride = a->src_c[0];
-  k.H = a->H; k.W = a->W; k.HW = a->H * a->W; k.M = (int)M; k.N = a->N;
+  k.H = a->Ho; k.W = a->Wo; k.HW = a->Ho * a->Wo; k.M = (int)M; k.N = a->N;
+  k.Hi = a->H; k.Wi = a->W; k.HWi = a->H * a->W;
   k.n_rt = a->N_pad / 32; k.n_ks = a->K_pad / 16;
   k.res_stride = a->res_stride; k.out_stride = a->out_stride; k.act = a->act;
   k.out_scale = a->out_scale;
@@ -516,6 +539,19 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
     k.n_rounds = slices / WK;
     return slices % WK == 0;
   };
+  if (s2) {
+    // stride 2: 4 x 16 or 8 x 16 output tiles by output width; a geometry the patch does not fit goes to the slot kernel
+    k.n_rounds = slices;
+    static const int alt = [] { const char* e = getenv("CF_CONV3_S2_ALT"); return e ? atoi(e) : 0; }();   // (dev A/B: other tile heights)
+    if (a->N_pad == 64) ok = try_launch<1, 4, 1, 2, 9, false, 2, true, 1, true>(k, a->B, st);
+    else if (a->N_pad == 128) ok = (alt & 1) ? try_launch<2, 2, 1, 2, 9, false, 2, true, 2, true>(k, a->B, st)
+                                             : try_launch<2, 2, 1, 2, 5, true, 2, true, 1, true>(k, a->B, st);
+    else if (a->N_pad >= 256) ok = (alt & 2) ? try_launch<4, 1, 1, 2, 3, true, 2, true, 1, true>(k, a->B, st)
+                                 : (alt & 4) ? try_launch<4, 2, 1, 2, 5, true, 1, true, 1, true>(k, a->B, st)
+                                             : try_launch<4, 1, 1, 2, 5, true, 2, true, 2, true>(k, a->B, st);
+    if (!ok) return cf_conv2d_f16x3(a, stream);
+    return cf_check_launch("cf_conv3x3_f16x3");
+  }
   // dev override (tools/bench_conv_cfg.py): CF_CONV3_CFG="WC,WP,WK[,T2]" forces one of the instantiated tilings
   static const int only_n = [] { const char* e = getenv("CF_CONV3_ONLY_N"); return e ? atoi(e) : 0; }();   // (dev: override one width only)
   if (const char* force = (only_n == 0 || only_n == a->N_pad) ? getenv("CF_CONV3_CFG") : nullptr) {

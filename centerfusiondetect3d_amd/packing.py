@@ -149,7 +149,7 @@ def pack_conv_f16(weight, bias, sources: Sequence[Source], stride=1, pad=None, d
     scaled by 2^s (max|w| -> [2^13, 2^14)), split into fp16 hi/lo and laid out in MFMA A-operand
     fragment order.  PackedConv.out_scale = 2^-(s+4) undoes the weight and activation scales.
 
-    A 3x3 / stride 1 / pad 1 convolution of ONE source with C % 16 == 0 is packed SLICE-MAJOR
+    A 3x3 / pad 1 convolution (stride 1 or 2) of ONE source with C % 16 == 0 is packed SLICE-MAJOR
     (k = (16-channel slice, tap, channel)): that is the order cf_conv3x3_f16x3 (LDS patch reuse)
     consumes, and since the slot table spells the same order out the generic kernel runs the very same
     weights (PackedConv.patch marks them)."""
@@ -158,7 +158,7 @@ def pack_conv_f16(weight, bias, sources: Sequence[Source], stride=1, pad=None, d
     pad = (kh - 1) // 2 * dilation if pad is None else pad
     n_pad = 32 if co <= 32 else ((co + 63) // 64) * 64
     slots, cols, c_lo = [], [], 0
-    patch = (kh == 3 and kw == 3 and stride == 1 and dilation == 1 and pad == 1 and len(sources) == 1
+    patch = (kh == 3 and kw == 3 and stride in (1, 2) and dilation == 1 and pad == 1 and len(sources) == 1
              and sources[0].channels % 16 == 0 and sources[0].c_base == 0 and sources[0].stride % 8 == 0)
     for si, s in enumerate(sources if not patch else ()):
         assert s.stride % 8 == 0 and s.c_base % 8 == 0 and s.channels % 8 == 0, "f16x3 sources need C % 8 == 0"

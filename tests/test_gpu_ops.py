@@ -648,6 +648,37 @@ def test_conv3x3_f16x3_patch(dev, B, Ci, Co, H, W, act, res, exact):
         assert torch.equal(out[..., :Co], out2[..., :Co])
 
 
+@pytest.mark.parametrize("B,Ci,Co,H,W", [
+    (2, 32, 64, 224, 400),     # level2.tree1.conv1 at the bench size: 8 x 16 output tiles, single-buffered patch
+    (2, 64, 128, 112, 200),    # level3: 4 x 16 tiles
+    (2, 128, 256, 56, 100),    # level4: output 28 x 50 (last tile column 2 of 16 wide)
+    (3, 256, 512, 28, 50),     # level5: output 14 x 25, two channel blocks
+    (1, 32, 64, 45, 67),       # odd input sizes: output 23 x 34, the last input row / column is a tap of the last output
+    (3, 64, 128, 17, 31),      # output 9 x 16
+    (1, 128, 256, 9, 130),     # output 5 x 65
+    (2, 16, 64, 8, 6),         # one slice, map smaller than a tile
+])
+def test_conv3x3_f16x3_stride2_patch(dev, B, Ci, Co, H, W):
+    """Stride-2 form of the LDS-patch kernel (odd / even column planes): fp32-level accuracy against float64 and the very
+    same bits as the generic slot kernel on the same slice-major weights."""
+    from centerfusiondetect3d_amd import ops, packing
+    x, w, b = F.relu(rnd(B, Ci, H, W, seed=1)) * 3, rnd(Co, Ci, 3, 3, seed=2, scale=(Ci * 9) ** -0.5), rnd(Co, seed=3)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), 2, 1))
+    pc = packing.pack_conv_f16(w, b, [packing.Source(Ci, Ci)], stride=2).to(dev)
+    assert pc.patch and pc.stride == 2
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    xd = nhwc(x).to(dev)
+    out = torch.full((B, Ho, Wo, Co), float("nan"), device=dev)
+    ops.conv2d_f16x3(pc, [xd], B, H, W, act=1, out=out, patch=True)
+    got = nchw(out).cpu().double()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print(f"[conv3x3 stride 2 patch] {Ci}->{Co} {H}x{W}: max|err|/max|ref| = {err:.2e}")
+    assert err < 1.5e-6, err
+    out2 = torch.zeros_like(out)
+    ops.conv2d_f16x3(pc, [xd], B, H, W, act=1, out=out2, patch=False)
+    assert torch.equal(out, out2)
+
+
 def test_conv2d_f16x3_root_concat(dev):
     from centerfusiondetect3d_amd import ops, packing
     B, H, W = 2, 14, 25

@@ -237,6 +237,15 @@ def test_no_exec_masked_prefetch_in_pinned_loops():
     assert "conv3x3_f16x3_kernel" in r.stdout and "head_patch16_kernel" in r.stdout
 
 
+def test_design_md_is_a_document_and_quotes_the_collected_test_counts():
+    """no table cell over 400 characters, no unfilled placeholder, and the two test counts of section 6 are
+    what pytest collects (tools/check_design.py --fix-counts writes them)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_design.py"), "--counts"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+
+
 def test_deform_conv2d_has_torchvisions_signature():
     """The operator-level drop-in binds exactly as torchvision.ops.deform_conv2d does (names, order, defaults), so the
     reference's keyword call (model/networks/dla.py:461-470) and positional calls both land; without a GPU it raises

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round profiles on the GPU box (one gpurun call): kernel trace + the three PMC passes of bench.py for the metric's
 # configuration (C2) and for BASELINE config 5 (3x896x1600, bs=8).  Outputs under gpurun_out/prof_<tag>/.
-#   bash tools/profile_round.sh r3
+#   bash tools/profile_round.sh r4
 # The program sits directly behind `--` (no env / bash -c hop under rocprofv3); PMC passes carry only --kernel-trace.
 set -e
-TAG=${1:-r3}
+TAG=${1:-r4}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -29,6 +29,10 @@ python3 tools/pmc_kernels.py $OUT/c5_sq --top 30 > $OUT/c5_pmc_mfma_util.txt
 for cfg in c2 c5; do
   python3 tools/prof_db.py $OUT/${cfg}_trace > $OUT/${cfg}_kernel_summary.txt || true
 done
+# per-launch tables (HIP events around every launch, one stream) and the test counts DESIGN.md quotes
+python3 tools/layer_times.py --iters 5 > $OUT/layer_times_bs16.txt 2>/dev/null || true
+python3 tools/layer_times.py --iters 5 --batch 1 > $OUT/layer_times_bs1.txt 2>/dev/null || true
+python3 tools/check_design.py --counts > $OUT/test_counts.txt 2>&1 || true
 # keep the merge small: the raw traces / databases stay on the box
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -type d -empty -delete
 ls -la $OUT
