@@ -546,9 +546,14 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
     if (a->N_pad == 64) ok = try_launch<1, 4, 1, 2, 9, false, 2, true, 1, true>(k, a->B, st);
     else if (a->N_pad == 128) ok = (alt & 1) ? try_launch<2, 2, 1, 2, 9, false, 2, true, 2, true>(k, a->B, st)
                                              : try_launch<2, 2, 1, 2, 5, true, 2, true, 1, true>(k, a->B, st);
-    else if (a->N_pad >= 256) ok = (alt & 2) ? try_launch<4, 1, 1, 2, 3, true, 2, true, 1, true>(k, a->B, st)
-                                 : (alt & 4) ? try_launch<4, 2, 1, 2, 5, true, 1, true, 1, true>(k, a->B, st)
-                                             : try_launch<4, 1, 1, 2, 5, true, 2, true, 2, true>(k, a->B, st);
+    else if (a->N_pad >= 256) {
+      // half-height tiles (2 x 16) while that grid still fits the chip in one round (level 5 of a bs <= 8 launch: 34.5 vs
+      // 47.9 us); same sums whatever the tile, so this may depend on the batch size (as the stride-1 small-grid rule)
+      const long half_tiles = (long)((a->Ho + 1) / 2) * ((a->Wo + 15) / 16) * a->B * ((a->N_pad + 255) / 256);
+      ok = ((alt & 2) || half_tiles <= 256) ? try_launch<4, 1, 1, 2, 3, true, 2, true, 1, true>(k, a->B, st)
+           : (alt & 4)                      ? try_launch<4, 2, 1, 2, 5, true, 1, true, 1, true>(k, a->B, st)
+                                            : try_launch<4, 1, 1, 2, 5, true, 2, true, 2, true>(k, a->B, st);
+    }
     if (!ok) return cf_conv2d_f16x3(a, stream);
     return cf_check_launch("cf_conv3x3_f16x3");
   }
