@@ -57,6 +57,12 @@ struct Conv3F {
   int x_stride, H, W, HW, M, N, n_rt, n_ks, n_rounds, res_stride, out_stride, act, PR;   // H, W, HW, M: the OUTPUT map
   int tiles_x, tiles_y;         // T2 only
   int Hi, Wi, HWi;              // S2 only: the input map (H, W are then the output's)
+  // ROOT only: the Tree's 1x1 Root over (this convolution's output x2, its residual x1) run from the epilogue
+  const unsigned char* root_w;  // [2][8 k-steps][2][64][8 f16]: K = (x2 channels 0..63, x1 channels 0..63)
+  const float* root_bias;
+  float* root_out;
+  int root_out_stride, root_act;
+  float root_scale;
   float out_scale;
 };
 
@@ -67,8 +73,14 @@ struct Conv3F {
 // CT = 32-pixel column tiles per wave: 2 (64 x 64 wave tiles, two waves per SIMD at 256 registers each) or 4 - the
 // ONE-WAVE-PER-SIMD form (MINB = 1, 512 registers: both accumulator sets of a 64-channel x 128-pixel tile, 256 registers,
 // sit in AGPRs; every weight fragment is fetched once per 128 pixels instead of once per 64).
-template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2, int CT = 2, bool S2 = false>
+// ROOT (64-channel BasicBlock conv2 of a one-level Tree, dla.py:105-118, 33-41): every wave holds ALL channels of its
+// pixels (WC = 1), so the Tree's Root - ReLU(W_root . [x2; x1] + b), x2 = this convolution's output, x1 = its residual -
+// runs from the epilogue: x2 (bias, residual, ReLU applied) and x1 are split to fp16 hi / lo into a wave-private LDS
+// tile that IS the B operand of the 1x1 GEMM, eight k-steps of MFMAs follow in the slot kernel's order, and only the
+// Root's output goes to HBM.  x2 is never written (unless p.out is given), x1 is read once for both uses, one launch less.
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2, int CT = 2, bool S2 = false, bool ROOT = false>
 __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
+  static_assert(!ROOT || (WC == 1 && WK == 1 && RT == 2 && !S2 && 64 * WC * WP * WK == 256), "Root fusion: one channel group of 64");
   constexpr int NT = 64 * WC * WP * WK;     // 4 waves, or 8 (WP doubled: two pixel groups share each weight fragment through L1)
   static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
   static_assert(!S2 || (T2 && WK == 1), "stride 2: tiled form, no K split");
@@ -342,6 +354,133 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
   // measured 8-26 % of a workgroup's time in this phase.  Each wave transposes its 32 pixels x 32*RT channels through
   // a private LDS tile instead (LDS executes a wave's instructions in order: no barrier) and then writes / reads whole
   // pixel rows: 8*RT lanes cover one contiguous run of RT*128 bytes.
+  if constexpr (ROOT) {
+    constexpr int EROW = RT * 128 + 16;      // transposition tile: 64 channels x 4 B + 16 per pixel row
+    constexpr int BROW = 144;                // B tile: 64 f16 + 16 B per pixel row and plane
+    constexpr int BPLANE = 32 * BROW;
+    constexpr int REG = 2 * BPLANE;          // one region (>= 32 * EROW): 9216 B
+    static_assert(REG >= 32 * EROW, "region holds a transposition tile");
+    constexpr int LPP = RT * 8, PPI = 64 / LPP;
+    asm volatile("; cf_epilogue_begin" ::: "memory");
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane = tid_e & 63, wave = __builtin_amdgcn_readfirstlane(tid_e >> 6), li = lane & 31, h = lane >> 5;
+    const int wp = wave;                     // (WC == 1, WK == 1)
+    unsigned char* r1 = smem + wave * 2 * REG;
+    unsigned char* r2 = r1 + REG;
+    const int chunk = lane % LPP, psub = lane / LPP;
+    const int n = chunk * 4;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+    const f32x4 rbias4 = *reinterpret_cast<const f32x4*>(p.root_bias + n);
+    auto pixel = [&](int ct, int ploc, int& m) {     // -> inside the map?
+      const int pl = wp * (32 * CT) + ct * 32 + ploc;
+      if (T2) {
+        const int y = ty0 + (pl >> 4), x = tx0 + (pl & 15);
+        m = m0 + y * p.W + x;
+        return y < p.H && x < p.W;
+      }
+      m = m0 + pl;
+      return m < p.M;
+    };
+    auto put_split = [&](unsigned char* reg, int ploc, const f32x4& v) {   // 4 channels of one pixel -> B tile (hi, lo)
+      const f32x4 xs = v * ASCALE;
+      uint2 hi2, lo2;
+      split2(xs[0], xs[1], hi2.x, lo2.x);
+      split2(xs[2], xs[3], hi2.y, lo2.y);
+      unsigned char* o = reg + ploc * BROW + n * 2;
+      *reinterpret_cast<uint2*>(o) = hi2;
+      *reinterpret_cast<uint2*>(o + BPLANE) = lo2;
+    };
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      cf_wave_lds_sync();                    // (every lane is done with the previous column tile's regions)
+      // 1. this convolution's accumulators -> region 1, transposed
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (accm[rt][ct][g * 4 + e] + accs[rt][ct][g * 4 + e]) * p.out_scale;
+          *reinterpret_cast<f32x4*>(r1 + li * EROW + (rt * 32 + 8 * g + 4 * h) * 4) = v;
+        }
+      cf_wave_lds_sync();
+      // 2. whole pixel rows: x2 = ReLU(conv + bias + x1) -> region 2 as a B tile; x1 stays in registers.  All rows are
+      //    read (and x1 requested) before the first is written, so no LDS read follows a write inside a phase
+      f32x4 x1v[32 / PPI], x2v[32 / PPI];
+#pragma unroll
+      for (int it = 0; it < 32 / PPI; ++it) {
+        const int ploc = it * PPI + psub;
+        int m;
+        const bool ok = pixel(ct, ploc, m);
+        x2v[it] = *reinterpret_cast<const f32x4*>(r1 + ploc * EROW + chunk * 16);
+        x1v[it] = ok ? *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.res_stride + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      cf_wave_lds_sync();                    // region 1 has been read by every lane: it becomes x1's B tile below
+#pragma unroll
+      for (int it = 0; it < 32 / PPI; ++it) {
+        const int ploc = it * PPI + psub;
+        f32x4 v = x2v[it] + bias4 + x1v[it];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        if (p.out) {
+          int m;
+          if (pixel(ct, ploc, m)) *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.out_stride + n) = v;
+        }
+        put_split(r2, ploc, v);
+        put_split(r1, ploc, x1v[it]);
+      }
+      cf_wave_lds_sync();
+      // 3. the Root: 8 k-steps (x2 channels, then x1 channels), the slot kernel's products in the slot kernel's order
+      f32x16 rm[RT], rs[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          rm[rt][r] = 0.0f;
+          rs[rt][r] = 0.0f;
+        }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const unsigned char* row = (ks < 4 ? r2 : r1) + li * BROW + (ks & 3) * 32 + h * 16;
+        const f16x8 xh = *reinterpret_cast<const f16x8*>(row);
+        const f16x8 xl = *reinterpret_cast<const f16x8*>(row + BPLANE);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const f16x8 ah = *wfrag16(p.root_w, rt, ks, 0, 8, lane);
+          const f16x8 al = *wfrag16(p.root_w, rt, ks, 1, 8, lane);
+          rs[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, rs[rt], 0, 0, 0);
+          rs[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, rs[rt], 0, 0, 0);
+          rm[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, rm[rt], 0, 0, 0);
+        }
+      }
+      cf_wave_lds_sync();                    // every B fragment has been read: region 2 becomes the output's transposition tile
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (rm[rt][g * 4 + e] + rs[rt][g * 4 + e]) * p.root_scale;
+          *reinterpret_cast<f32x4*>(r2 + li * EROW + (rt * 32 + 8 * g + 4 * h) * 4) = v;
+        }
+      cf_wave_lds_sync();
+#pragma unroll
+      for (int it = 0; it < 32 / PPI; ++it) {
+        const int ploc = it * PPI + psub;
+        int m;
+        const bool ok = pixel(ct, ploc, m);
+        f32x4 v = *reinterpret_cast<const f32x4*>(r2 + ploc * EROW + chunk * 16) + rbias4;
+        if (p.root_act == CF_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+        }
+        if (ok) *reinterpret_cast<f32x4*>(p.root_out + (size_t)m * p.root_out_stride + n) = v;
+      }
+    }
+    return;
+  }
+
   constexpr bool coalesced = WK == 1 && NT == 256;   // (8-wave configuration: measured no better; K-split waves: direct)
   if (coalesced && w_ok) {
     constexpr int EROW = RT * 128 + 16;      // bytes per pixel row of the tile: +16 B so that 16 lanes hit 64 banks
@@ -460,7 +599,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
 #endif
 }
 
-template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2 = false, int CT = 2, bool S2 = false>
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2 = false, int CT = 2, bool S2 = false, bool ROOT = false>
 bool try_launch(Conv3F k, int batch, hipStream_t st) {
   constexpr int R = 32 * CT * WP, ROWB = 64 * WK + 16;
   long blocks;
@@ -482,7 +621,12 @@ bool try_launch(Conv3F k, int batch, hipStream_t st) {
   if (WK == 1 && NT == 256 && dyn < epi) dyn = epi;
   if (dyn > 160 * 1024) return false;
   if (S2 && MINB >= 2 && dyn > 80 * 1024) return false;
-  auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB, T2, CT, S2>;
+  if (ROOT) {
+    constexpr size_t root_lds = (size_t)4 * 2 * 9216;   // four waves x two regions
+    if (dyn < root_lds) dyn = root_lds;
+    if (dyn > 80 * 1024) return false;
+  }
+  auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB, T2, CT, S2, ROOT>;
   static CfLdsLimit lds_limit;                // (one per template instantiation)
   lds_limit.ensure(kernel, dyn, 65536);
   const dim3 grid((unsigned)blocks, (unsigned)((k.n_rt + WC * RT - 1) / (WC * RT)));
@@ -499,7 +643,8 @@ bool tiles_fit(int H, int W) {
 }  // namespace
 
 // A geometry that fits no patch configuration is forwarded to cf_conv2d_f16x3 (same packed weights).
-extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
+// root != nullptr (cf_conv3x3_root_f16x3, already validated): try the fused conv2 + Root launch first; *fused says whether it ran.
+static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, bool* fused, void* stream) {
   CF_REQUIRE(a != nullptr, "cf_conv3x3_f16x3: null args");
   CF_REQUIRE(a->n_src == 1 && a->src[0] && a->src_c[0] > 0 && a->src_c[0] % 4 == 0, "cf_conv3x3_f16x3: one fp32 NHWC source");
   const bool s2 = a->stride == 2;
@@ -539,6 +684,22 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
     k.n_rounds = slices / WK;
     return slices % WK == 0;
   };
+  if (root && !s2 && a->N_pad == 64 && cfg(1)) {
+    Conv3F kr = k;
+    kr.out = nullptr;                        // x2 stays on the chip
+    kr.root_w = reinterpret_cast<const unsigned char*>(root->weight);
+    kr.root_bias = root->bias;
+    kr.root_out = root->out;
+    kr.root_out_stride = root->out_stride;
+    kr.root_act = root->act;
+    kr.root_scale = root->out_scale;
+    const bool t2r = (long)a->H * a->W >= 4096 && tiles_fit(a->H, a->W);
+    if ((t2r && try_launch<1, 4, 1, 2, 6, true, 2, true, 2, false, true>(kr, B, st)) ||
+        try_launch<1, 4, 1, 2, 6, true, 2, false, 2, false, true>(kr, B, st)) {
+      *fused = true;
+      return cf_check_launch("cf_conv3x3_root_f16x3");
+    }
+  }
   if (s2) {
     // stride 2: 4 x 16 or 8 x 16 output tiles by output width; a geometry the patch does not fit goes to the slot kernel
     k.n_rounds = slices;
@@ -663,3 +824,31 @@ extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) {
   if (!ok) return cf_conv2d_f16x3(a, stream);
   return cf_check_launch("cf_conv3x3_f16x3");
 }
+
+extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) { return conv3x3_impl(a, nullptr, nullptr, stream); }
+
+// BasicBlock conv2 (+ residual + ReLU) and the Tree's Root over (conv2's output, conv2's residual) as ONE launch where
+// a workgroup holds every channel of its pixels (64-channel layers); everything else runs the two launches.  Same
+// bits either way (the Root's products and their order are the slot kernel's).
+extern "C" int cf_conv3x3_root_f16x3(const cf_conv_args* a, const cf_conv_args* r, void* stream) {
+  CF_REQUIRE(a != nullptr && r != nullptr, "cf_conv3x3_root_f16x3: null args");
+  CF_REQUIRE(a->out && a->residual && a->act == CF_ACT_RELU && a->stride == 1,
+             "cf_conv3x3_root_f16x3: conv2 needs its output buffer (fallback), a residual and ReLU");
+  CF_REQUIRE(r->n_src == 2 && r->src[0] == a->out && r->src[1] == a->residual && r->src_c[0] == a->out_stride &&
+                 r->src_c[1] == a->res_stride,
+             "cf_conv3x3_root_f16x3: the Root's sources must be (conv2's output, conv2's residual)");
+  CF_REQUIRE(r->B == a->B && r->H == a->Ho && r->W == a->Wo && r->Ho == r->H && r->Wo == r->W && r->stride == 1,
+             "cf_conv3x3_root_f16x3: the Root is a 1x1 convolution on conv2's output map");
+  CF_REQUIRE(r->weight && r->bias && r->out && !r->residual && r->out_scale > 0.0f &&
+                 (r->act == CF_ACT_NONE || r->act == CF_ACT_RELU) && r->out_layout == CF_LAYOUT_NHWC &&
+                 r->out_stride >= r->N && r->out_stride % 4 == 0,
+             "cf_conv3x3_root_f16x3: bad Root argument block");
+  bool fused = false;
+  const bool fusable = a->N == 64 && a->N_pad == 64 && r->N == 64 && r->N_pad == 64 && r->K_pad == 128 &&
+                       a->res_stride % 4 == 0 && r->out_stride % 4 == 0;
+  static const int fuse_on = [] { const char* e = getenv("CF_ROOT_FUSE"); return e ? atoi(e) : 1; }();   // (dev A/B)
+  const int rc = conv3x3_impl(a, (fusable && fuse_on) ? r : nullptr, &fused, stream);
+  if (rc != CF_OK || fused) return rc;
+  return cf_conv2d_f16x3(r, stream);
+}
+

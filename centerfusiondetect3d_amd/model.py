@@ -325,6 +325,26 @@ class _Plan:
                 children.append(bottom)
             if levels == 1:
                 x1 = block(p + ".tree1", x, residual)
+                pc2, pcr = pk[p + ".tree2.conv2"], pk[p + ".root"]
+                if (model.root_fuse and model.conv_patch and not children and pc2.out_scale > 0 and pcr.out_scale > 0
+                        and getattr(pc2, "patch", False) and pc2.stride == 1):
+                    # tree2.conv2 and the Root as ONE step (cf_conv3x3_root_f16x3): x2 is never written where a workgroup
+                    # holds every channel of its pixels (the 64-channel level 2); the library runs the two launches for
+                    # every other shape, bit-identical either way
+                    _, h, w, _ = x1.shape
+                    t, _ = conv(p + ".tree2.conv1", [x1], h, w)
+                    x2, o = buf(B, h, w, pc2.n), buf(B, h, w, pcr.n)
+                    a2 = ops.conv_args(pc2, [t], [t.shape[-1]], B, h, w, x2, pc2.n, ACT_RELU, x1, x1.shape[-1],
+                                       LAYOUT_NHWC, None, 0, False)
+                    ar = ops.conv_args(pcr, [x2, x1], [pc2.n, x1.shape[-1]], B, h, w, o, pcr.n, ACT_RELU, None, 0,
+                                       LAYOUT_NHWC, None, 0, False)
+                    self.keep += [a2, ar]
+                    name = p + ".tree2.conv2+root"
+                    self.step_index[name] = len(self.steps)
+                    self.step_flops[name] = 2.0 * B * h * w * (pc2.n * 9 * sum(int(c) for c in pc2.real_cin)
+                                                               + pcr.n * sum(int(c) for c in pcr.real_cin))
+                    self.add_step((self.lib.cf_conv3x3_root_f16x3, C.byref(a2), C.byref(ar)))
+                    return o
                 x2 = block(p + ".tree2", x1, None)
                 _, h, w, _ = x2.shape
                 o, _ = conv(p + ".root", [x2, x1, *children], h, w)
@@ -712,6 +732,7 @@ class DLASeg(nn.Module):
                                  # static buffers) instead of ~100 launches from Python (_forward_graph)
         self.stem_fused = True   # with conv_f16: base_layer + level0 + level1 in one launch (cf_stem.hip)
         self.conv_patch = True   # 3x3 stride-1 f16x3 convs: LDS patch reuse (cf_conv3x3_f16.hip)
+        self.root_fuse = True    # one-level Trees without children: tree2.conv2 + Root as one step (cf_conv3x3_root_f16x3)
         self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)
         self.heads_fused = True  # with heads_bf16: one launch per head group, hidden maps stay in LDS
         self.heads_mfma16 = True # fused heads: first layer + register-fed output layer on v_mfma_f32_16x16x32_bf16 (the

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 2 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us */
+#define CF_ABI_VERSION 3 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3 */
 
 #define CF_OK 0
 #define CF_EINVAL (-22)
@@ -125,6 +125,18 @@ int cf_conv2d_f16x3(const cf_conv_args* a, void* stream);
  * wide for the patch (about W > 250) are forwarded to cf_conv2d_f16x3.  Carries the BasicBlock
  * convolutions (model/networks/dla.py:42-62) and DeformConv.conv_offset_mask (dla.py:406-414). */
 int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream);
+/* (ABI 3) also the 3x3 / stride 2 / pad 1 case - the BasicBlock conv1 that opens a DLA level (dla.py:124-145): odd / even
+ * input columns as two planes of the LDS patch; same packing, same result as cf_conv2d_f16x3. */
+
+/* cf_conv3x3_root_f16x3: BasicBlock.conv2 (+ residual + ReLU; dla.py:33-41) of a one-level Tree's tree2 and the Tree's
+ * Root (1x1 convolution + BN + ReLU over cat(x2, x1); dla.py:105-118, 81-96 with children = []) in ONE launch:
+ *   x2 = ReLU(conv3x3(t, W2) + b2 + x1);  out = act(W_root . [x2; x1] + b_root)
+ * `conv` is conv2's argument block as for cf_conv3x3_f16x3 (residual = x1, act = RELU; `out` = a buffer for x2, written
+ * only when the call falls back); `root` is the Root's block as for cf_conv2d_f16x3 with src[0] = conv->out,
+ * src[1] = conv->residual.  Where a workgroup holds every channel of its pixels (64-channel layers) x2 never leaves the
+ * chip: it is split to fp16 hi / lo into LDS as the B operand of the Root's GEMM, whose products and order are those of
+ * cf_conv2d_f16x3 - so the result equals the two launches bit for bit, which is what runs for every other shape. */
+int cf_conv3x3_root_f16x3(const cf_conv_args* conv, const cf_conv_args* root, void* stream);
 
 /* cf_split_bf16: fp32 NHWC [M][in_stride] (C used) -> split-bf16 [M][2][Cs], channels C..Cs-1 zero. */
 int cf_split_bf16(const float* x, void* out, long M, int C, int in_stride, int Cs, void* stream);

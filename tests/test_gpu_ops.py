@@ -679,6 +679,40 @@ def test_conv3x3_f16x3_stride2_patch(dev, B, Ci, Co, H, W):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("B,H,W,fused", [
+    (2, 112, 200, True),       # level 2 at the bench size: 16 x 16 tiles of one image
+    (3, 37, 41, True),         # flat 256-pixel runs, ragged last run, image borders inside a run
+    (1, 128, 160, True),       # tiled, last tile column / row partly outside
+    (1, 5, 300, False),        # too wide for the LDS patch: the library runs the two launches
+])
+def test_conv3x3_root_fused_equals_two_launches(dev, B, H, W, fused):
+    """cf_conv3x3_root_f16x3: tree2.conv2 (+ x1, ReLU) and the Tree's Root over (x2, x1) in one launch - the same bits as
+    cf_conv3x3_f16x3 followed by cf_conv2d_f16x3 on the same packed weights, x2 not written when fused, and fp32-level
+    accuracy against float64."""
+    from centerfusiondetect3d_amd import ops, packing
+    C_ = 64
+    t, x1 = F.relu(rnd(B, C_, H, W, seed=1)) * 2, F.relu(rnd(B, C_, H, W, seed=2)) * 2
+    w2, b2 = rnd(C_, C_, 3, 3, seed=3, scale=(C_ * 9) ** -0.5), rnd(C_, seed=4)
+    wr, br = rnd(C_, 2 * C_, 1, 1, seed=5, scale=(2 * C_) ** -0.5), rnd(C_, seed=6)
+    x2_ref = F.relu(F.conv2d(t.double(), w2.double(), b2.double(), 1, 1) + x1.double())
+    ref = F.relu(F.conv2d(torch.cat([x2_ref, x1.double()], 1), wr.double(), br.double()))
+    pc2 = packing.pack_conv_f16(w2, b2, [packing.Source(C_, C_)]).to(dev)
+    pcr = packing.pack_conv_f16(wr, br, [packing.Source(C_, C_), packing.Source(C_, C_)]).to(dev)
+    assert pc2.patch and pcr.k_pad == 128
+    td, x1d = nhwc(t).to(dev), nhwc(x1).to(dev)
+    x2_buf = torch.full((B, H, W, C_), float("nan"), device=dev)
+    out, _ = ops.conv3x3_root_f16x3(pc2, pcr, td, x1d, x2_out=x2_buf)
+    x2_two = ops.conv2d_f16x3(pc2, [td], B, H, W, act=1, residual=x1d)
+    out_two = ops.conv2d_f16x3(pcr, [x2_two, x1d], B, H, W, act=1)
+    assert torch.equal(out, out_two)
+    if fused:
+        assert torch.isnan(x2_buf).all()                 # x2 never left the chip
+    else:
+        assert torch.equal(x2_buf, x2_two)
+    err = float((nchw(out).cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+
+
 def test_conv2d_f16x3_root_concat(dev):
     from centerfusiondetect3d_amd import ops, packing
     B, H, W = 2, 14, 25
