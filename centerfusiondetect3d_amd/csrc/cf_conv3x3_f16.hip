@@ -73,14 +73,16 @@ struct Conv3F {
 // CT = 32-pixel column tiles per wave: 2 (64 x 64 wave tiles, two waves per SIMD at 256 registers each) or 4 - the
 // ONE-WAVE-PER-SIMD form (MINB = 1, 512 registers: both accumulator sets of a 64-channel x 128-pixel tile, 256 registers,
 // sit in AGPRs; every weight fragment is fetched once per 128 pixels instead of once per 64).
-// ROOT (64-channel BasicBlock conv2 of a one-level Tree, dla.py:105-118, 33-41): every wave holds ALL channels of its
-// pixels (WC = 1), so the Tree's Root - ReLU(W_root . [x2; x1] + b), x2 = this convolution's output, x1 = its residual -
-// runs from the epilogue: x2 (bias, residual, ReLU applied) and x1 are split to fp16 hi / lo into a wave-private LDS
-// tile that IS the B operand of the 1x1 GEMM, eight k-steps of MFMAs follow in the slot kernel's order, and only the
-// Root's output goes to HBM.  x2 is never written (unless p.out is given), x1 is read once for both uses, one launch less.
+// ROOT (BasicBlock conv2 of a one-level Tree without children, dla.py:105-118, 33-41; N = 64 WC channels, all of them in
+// this workgroup): the Tree's Root - ReLU(W_root . [x2; x1] + b), x2 = this convolution's output, x1 = its residual -
+// runs from the epilogue.  Every wave splits its 64 channels of x2 (bias, residual, ReLU applied) and of x1 to fp16
+// hi / lo into its two LDS regions, which ARE pieces of the B operand of the 1x1 GEMM; after a barrier (WC > 1: the WC
+// waves of a pixel group read each other's pieces) 8 WC k-steps of MFMAs follow in the slot kernel's order, each wave
+// producing its own 64 output channels.  Only the Root's output goes to HBM: x2 is never written (unless p.out is
+// given), x1 is read once for both uses, one launch less.
 template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2, int CT = 2, bool S2 = false, bool ROOT = false>
 __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
-  static_assert(!ROOT || (WC == 1 && WK == 1 && RT == 2 && !S2 && 64 * WC * WP * WK == 256), "Root fusion: one channel group of 64");
+  static_assert(!ROOT || (WK == 1 && RT == 2 && !S2 && 64 * WC * WP * WK == 256), "Root fusion: 64-channel waves, 4 waves, every channel of a pixel in the workgroup");
   constexpr int NT = 64 * WC * WP * WK;     // 4 waves, or 8 (WP doubled: two pixel groups share each weight fragment through L1)
   static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
   static_assert(!S2 || (T2 && WK == 1), "stride 2: tiled form, no K split");
@@ -365,13 +367,18 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
     const int lane = tid_e & 63, wave = __builtin_amdgcn_readfirstlane(tid_e >> 6), li = lane & 31, h = lane >> 5;
-    const int wp = wave;                     // (WC == 1, WK == 1)
+    const int wp = wave % WP, wc = wave / WP;   // (WK == 1)
     unsigned char* r1 = smem + wave * 2 * REG;
     unsigned char* r2 = r1 + REG;
     const int chunk = lane % LPP, psub = lane / LPP;
-    const int n = chunk * 4;
+    const int n = wc * 64 + chunk * 4;       // this lane's 4 channels: of x2 / x1 (phases 1-2) and of the Root's output (phase 4)
+    const int nl = chunk * 4;                // ... inside the wave's 64
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
     const f32x4 rbias4 = *reinterpret_cast<const f32x4*>(p.root_bias + n);
+    auto group_sync = [&]() {                // the WC waves of a pixel group exchange data (WC == 1: the wave alone)
+      if (WC > 1) __syncthreads();
+      else cf_wave_lds_sync();
+    };
     auto pixel = [&](int ct, int ploc, int& m) {     // -> inside the map?
       const int pl = wp * (32 * CT) + ct * 32 + ploc;
       if (T2) {
@@ -387,13 +394,24 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
       uint2 hi2, lo2;
       split2(xs[0], xs[1], hi2.x, lo2.x);
       split2(xs[2], xs[3], hi2.y, lo2.y);
-      unsigned char* o = reg + ploc * BROW + n * 2;
+      unsigned char* o = reg + ploc * BROW + nl * 2;
       *reinterpret_cast<uint2*>(o) = hi2;
       *reinterpret_cast<uint2*>(o + BPLANE) = lo2;
     };
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      cf_wave_lds_sync();                    // (every lane is done with the previous column tile's regions)
+      group_sync();                          // (everybody is done with the previous column tile's regions)
+      // the Root's first weight fragments are requested now: they arrive under phases 1-2
+      f16x8 rwh[4][RT], rwl[4][RT];          // (set ks % 4; the loop is unrolled by 4, so the set index is static)
+      auto load_rw = [&](f16x8 (&dh)[RT], f16x8 (&dl)[RT], int ks) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          dh[rt] = *wfrag16(p.root_w, wc * RT + rt, ks, 0, 8 * WC, lane);
+          dl[rt] = *wfrag16(p.root_w, wc * RT + rt, ks, 1, 8 * WC, lane);
+        }
+      };
+      load_rw(rwh[0], rwl[0], 0);
+      load_rw(rwh[1], rwl[1], 1);
       // 1. this convolution's accumulators -> region 1, transposed
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -430,8 +448,9 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
         put_split(r2, ploc, v);
         put_split(r1, ploc, x1v[it]);
       }
-      cf_wave_lds_sync();
-      // 3. the Root: 8 k-steps (x2 channels, then x1 channels), the slot kernel's products in the slot kernel's order
+      group_sync();
+      // 3. the Root: 8 WC k-steps - x2 channels in order (the pieces of waves wc' = 0 .. WC-1 of this pixel group), then
+      //    x1 channels - with the slot kernel's products in the slot kernel's order; this wave's 64 output channels
       f32x16 rm[RT], rs[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -440,21 +459,21 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
           rm[rt][r] = 0.0f;
           rs[rt][r] = 0.0f;
         }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const unsigned char* row = (ks < 4 ? r2 : r1) + li * BROW + (ks & 3) * 32 + h * 16;
+#pragma unroll 4
+      for (int ks = 0; ks < 8 * WC; ++ks) {
+        const int piece = (ks >> 2) % WC, src = ks / (4 * WC);          // whose region, x2 (region 2) or x1 (region 1)
+        const unsigned char* row = smem + ((piece * WP + wp) * 2 + (src == 0 ? 1 : 0)) * REG + li * BROW + (ks & 3) * 32 + h * 16;
         const f16x8 xh = *reinterpret_cast<const f16x8*>(row);
         const f16x8 xl = *reinterpret_cast<const f16x8*>(row + BPLANE);
+        load_rw(rwh[(ks + 2) % 4], rwl[(ks + 2) % 4], min(ks + 2, 8 * WC - 1));   // weights two k-steps ahead
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          const f16x8 ah = *wfrag16(p.root_w, rt, ks, 0, 8, lane);
-          const f16x8 al = *wfrag16(p.root_w, rt, ks, 1, 8, lane);
-          rs[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, rs[rt], 0, 0, 0);
-          rs[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, rs[rt], 0, 0, 0);
-          rm[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, rm[rt], 0, 0, 0);
+          rs[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rwl[ks % 4][rt], xh, rs[rt], 0, 0, 0);
+          rs[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rwh[ks % 4][rt], xl, rs[rt], 0, 0, 0);
+          rm[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rwh[ks % 4][rt], xh, rm[rt], 0, 0, 0);
         }
       }
-      cf_wave_lds_sync();                    // every B fragment has been read: region 2 becomes the output's transposition tile
+      group_sync();                          // every B fragment has been read: region 2 becomes the output's transposition tile
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -684,7 +703,7 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, bool* f
     k.n_rounds = slices / WK;
     return slices % WK == 0;
   };
-  if (root && !s2 && a->N_pad == 64 && cfg(1)) {
+  if (root && !s2 && cfg(1)) {
     Conv3F kr = k;
     kr.out = nullptr;                        // x2 stays on the chip
     kr.root_w = reinterpret_cast<const unsigned char*>(root->weight);
@@ -694,8 +713,20 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, bool* f
     kr.root_act = root->act;
     kr.root_scale = root->out_scale;
     const bool t2r = (long)a->H * a->W >= 4096 && tiles_fit(a->H, a->W);
-    if ((t2r && try_launch<1, 4, 1, 2, 6, true, 2, true, 2, false, true>(kr, B, st)) ||
-        try_launch<1, 4, 1, 2, 6, true, 2, false, 2, false, true>(kr, B, st)) {
+    // (launches small enough for the one-round half tiles below keep those and the two launches: same bits)
+    const long half_tiles = (long)((a->H + 7) / 8) * ((a->W + 15) / 16) * B;
+    bool okr = false;
+    if (a->N_pad == 64 && half_tiles > 256)
+      okr = (t2r && try_launch<1, 4, 1, 2, 6, true, 2, true, 2, false, true>(kr, B, st)) ||
+            try_launch<1, 4, 1, 2, 6, true, 2, false, 2, false, true>(kr, B, st);
+    else if (a->N_pad == 128 && 2 * half_tiles > 256)
+      okr = (t2r && try_launch<2, 2, 1, 2, 4, true, 2, true, 2, false, true>(kr, B, st)) ||
+            try_launch<2, 2, 1, 2, 6, true, 2, false, 2, false, true>(kr, B, st) ||
+            try_launch<2, 2, 1, 2, 4, true, 2, true, 2, false, true>(kr, B, st);
+    else if (a->N_pad == 256 && (long)a->H * a->W > 512 && (M + 31) / 32 > 256)
+      okr = try_launch<4, 1, 1, 2, 4, true, 2, false, 2, false, true>(kr, B, st) ||
+            try_launch<4, 1, 1, 2, 2, true, 2, true, 2, false, true>(kr, B, st);
+    if (okr) {
       *fused = true;
       return cf_check_launch("cf_conv3x3_root_f16x3");
     }
@@ -844,8 +875,8 @@ extern "C" int cf_conv3x3_root_f16x3(const cf_conv_args* a, const cf_conv_args* 
                  r->out_stride >= r->N && r->out_stride % 4 == 0,
              "cf_conv3x3_root_f16x3: bad Root argument block");
   bool fused = false;
-  const bool fusable = a->N == 64 && a->N_pad == 64 && r->N == 64 && r->N_pad == 64 && r->K_pad == 128 &&
-                       a->res_stride % 4 == 0 && r->out_stride % 4 == 0;
+  const bool fusable = (a->N == 64 || a->N == 128 || a->N == 256) && a->N_pad == a->N && r->N == a->N &&
+                       r->N_pad == a->N && r->K_pad == 2 * a->N && a->res_stride % 4 == 0 && r->out_stride % 4 == 0;
   static const int fuse_on = [] { const char* e = getenv("CF_ROOT_FUSE"); return e ? atoi(e) : 1; }();   // (dev A/B)
   const int rc = conv3x3_impl(a, (fusable && fuse_on) ? r : nullptr, &fused, stream);
   if (rc != CF_OK || fused) return rc;

@@ -133,7 +133,7 @@ int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream);
  *   x2 = ReLU(conv3x3(t, W2) + b2 + x1);  out = act(W_root . [x2; x1] + b_root)
  * `conv` is conv2's argument block as for cf_conv3x3_f16x3 (residual = x1, act = RELU; `out` = a buffer for x2, written
  * only when the call falls back); `root` is the Root's block as for cf_conv2d_f16x3 with src[0] = conv->out,
- * src[1] = conv->residual.  Where a workgroup holds every channel of its pixels (64-channel layers) x2 never leaves the
+ * src[1] = conv->residual.  Where a workgroup holds every channel of its pixels (64 / 128 / 256-channel layers) x2 never leaves the
  * chip: it is split to fp16 hi / lo into LDS as the B operand of the Root's GEMM, whose products and order are those of
  * cf_conv2d_f16x3 - so the result equals the two launches bit for bit, which is what runs for every other shape. */
 int cf_conv3x3_root_f16x3(const cf_conv_args* conv, const cf_conv_args* root, void* stream);
