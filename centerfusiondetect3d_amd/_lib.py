@@ -82,7 +82,7 @@ SYMBOLS = {
     "cf_conv2d_bf16x3": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_conv2d_f16x3": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_conv3x3_f16x3": (_i, [C.POINTER(ConvArgs), _f]),
-    "cf_conv3x3_root_f16x3": (_i, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), _f]),
+    "cf_conv3x3_root_f16x3": (_i, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.POINTER(C.c_int32), _f]),
     "cf_stem_fused": (_i, [C.POINTER(StemArgs), _f]),
     "cf_split_bf16": (_i, [_f, _f, C.c_long, _i, _i, _i, _f]),
     "cf_head_tail": (_i, [C.POINTER(HeadTailArgs), _f]),

@@ -63,6 +63,10 @@ struct Conv3F {
   float* root_out;
   int root_out_stride, root_act;
   float root_scale;
+  // ... and the Root's further sources (the Tree's children: dla.py:109-117), K order behind x2 and x1
+  const float* root_xsrc[2];
+  int root_xsrc_c[2], root_xsrc_ch[2];   // floats per pixel, channels (multiples of 64)
+  int root_nks;                          // k-steps of the whole Root: (2 N + children's channels) / 16
   float out_scale;
 };
 
@@ -406,8 +410,8 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
       auto load_rw = [&](f16x8 (&dh)[RT], f16x8 (&dl)[RT], int ks) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          dh[rt] = *wfrag16(p.root_w, wc * RT + rt, ks, 0, 8 * WC, lane);
-          dl[rt] = *wfrag16(p.root_w, wc * RT + rt, ks, 1, 8 * WC, lane);
+          dh[rt] = *wfrag16(p.root_w, wc * RT + rt, ks, 0, p.root_nks, lane);
+          dl[rt] = *wfrag16(p.root_w, wc * RT + rt, ks, 1, p.root_nks, lane);
         }
       };
       load_rw(rwh[0], rwl[0], 0);
@@ -465,12 +469,60 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
         const unsigned char* row = smem + ((piece * WP + wp) * 2 + (src == 0 ? 1 : 0)) * REG + li * BROW + (ks & 3) * 32 + h * 16;
         const f16x8 xh = *reinterpret_cast<const f16x8*>(row);
         const f16x8 xl = *reinterpret_cast<const f16x8*>(row + BPLANE);
-        load_rw(rwh[(ks + 2) % 4], rwl[(ks + 2) % 4], min(ks + 2, 8 * WC - 1));   // weights two k-steps ahead
+        load_rw(rwh[(ks + 2) % 4], rwl[(ks + 2) % 4], min(ks + 2, p.root_nks - 1));   // weights two k-steps ahead
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           rs[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rwl[ks % 4][rt], xh, rs[rt], 0, 0, 0);
           rs[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rwh[ks % 4][rt], xl, rs[rt], 0, 0, 0);
           rm[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rwh[ks % 4][rt], xh, rm[rt], 0, 0, 0);
+        }
+      }
+      // 3b. the Tree's children (further sources of the Root): 64-channel pieces, WC at a time - wave wc fetches piece
+      //     e0 + wc of these 32 pixels from HBM (whole rows, as the residual), splits it into its region 2, and after the
+      //     barrier every wave multiplies the round's pieces in K order.  The weight fragments keep rotating through the four sets (a
+      //     piece is 4 k-steps, so the set index stays static).
+      {
+        const int n_extra = (p.root_nks - 8 * WC) >> 2;      // 64-channel pieces of the children
+        const int ch0 = p.root_xsrc_ch[0] >> 6;               // pieces of the first child
+        int ksx = 8 * WC;
+        for (int e0 = 0; e0 < n_extra; e0 += WC) {
+          group_sync();                        // the previous k-steps' fragments have been read: regions are free
+          const int e = e0 + wc;
+          if (e < n_extra) {
+            // (the rows are requested here, not a round ahead or in front of the barrier: eight more row registers live
+            //  across either spill; the CU's other workgroup covers the latency)
+            const bool first = e < ch0;
+            const float* xs = first ? p.root_xsrc[0] : p.root_xsrc[1];
+            const int xc = first ? p.root_xsrc_c[0] : p.root_xsrc_c[1];
+            const int off = (first ? e : e - ch0) * 64 + nl;
+            f32x4 xv[32 / PPI];
+#pragma unroll
+            for (int it = 0; it < 32 / PPI; ++it) {
+              int m;
+              const bool ok = pixel(ct, it * PPI + psub, m);
+              xv[it] = ok ? *reinterpret_cast<const f32x4*>(xs + (size_t)m * xc + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int it = 0; it < 32 / PPI; ++it) put_split(r2, it * PPI + psub, xv[it]);
+          }
+          group_sync();
+          const int np = min(WC, n_extra - e0);
+          for (int i = 0; i < np; ++i) {
+            const unsigned char* reg = smem + ((i * WP + wp) * 2 + 1) * REG + li * BROW + h * 16;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const f16x8 xh = *reinterpret_cast<const f16x8*>(reg + kk * 32);
+              const f16x8 xl = *reinterpret_cast<const f16x8*>(reg + kk * 32 + BPLANE);
+              load_rw(rwh[(kk + 2) % 4], rwl[(kk + 2) % 4], min(ksx + kk + 2, p.root_nks - 1));
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt) {
+                rs[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rwl[kk][rt], xh, rs[rt], 0, 0, 0);
+                rs[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rwh[kk][rt], xl, rs[rt], 0, 0, 0);
+                rm[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rwh[kk][rt], xh, rm[rt], 0, 0, 0);
+              }
+            }
+            ksx += 4;
+          }
         }
       }
       group_sync();                          // every B fragment has been read: region 2 becomes the output's transposition tile
@@ -663,7 +715,7 @@ bool tiles_fit(int H, int W) {
 
 // A geometry that fits no patch configuration is forwarded to cf_conv2d_f16x3 (same packed weights).
 // root != nullptr (cf_conv3x3_root_f16x3, already validated): try the fused conv2 + Root launch first; *fused says whether it ran.
-static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, bool* fused, void* stream) {
+static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const int32_t* root_ch, bool* fused, void* stream) {
   CF_REQUIRE(a != nullptr, "cf_conv3x3_f16x3: null args");
   CF_REQUIRE(a->n_src == 1 && a->src[0] && a->src_c[0] > 0 && a->src_c[0] % 4 == 0, "cf_conv3x3_f16x3: one fp32 NHWC source");
   const bool s2 = a->stride == 2;
@@ -712,6 +764,12 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, bool* f
     kr.root_out_stride = root->out_stride;
     kr.root_act = root->act;
     kr.root_scale = root->out_scale;
+    kr.root_nks = root->K_pad / 16;
+    for (int i = 0; i < 2; ++i) {
+      kr.root_xsrc[i] = i + 2 < root->n_src ? root->src[i + 2] : nullptr;
+      kr.root_xsrc_c[i] = i + 2 < root->n_src ? root->src_c[i + 2] : 0;
+      kr.root_xsrc_ch[i] = i + 2 < root->n_src ? root_ch[i + 2] : 0;
+    }
     const bool t2r = (long)a->H * a->W >= 4096 && tiles_fit(a->H, a->W);
     // (launches small enough for the one-round half tiles below keep those and the two launches: same bits)
     const long half_tiles = (long)((a->H + 7) / 8) * ((a->W + 15) / 16) * B;
@@ -856,30 +914,38 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, bool* f
   return cf_check_launch("cf_conv3x3_f16x3");
 }
 
-extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) { return conv3x3_impl(a, nullptr, nullptr, stream); }
+extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) { return conv3x3_impl(a, nullptr, nullptr, nullptr, stream); }
 
 // BasicBlock conv2 (+ residual + ReLU) and the Tree's Root over (conv2's output, conv2's residual) as ONE launch where
 // a workgroup holds every channel of its pixels (64-channel layers); everything else runs the two launches.  Same
 // bits either way (the Root's products and their order are the slot kernel's).
-extern "C" int cf_conv3x3_root_f16x3(const cf_conv_args* a, const cf_conv_args* r, void* stream) {
-  CF_REQUIRE(a != nullptr && r != nullptr, "cf_conv3x3_root_f16x3: null args");
+extern "C" int cf_conv3x3_root_f16x3(const cf_conv_args* a, const cf_conv_args* r, const int32_t* root_channels, void* stream) {
+  CF_REQUIRE(a != nullptr && r != nullptr && root_channels != nullptr, "cf_conv3x3_root_f16x3: null args");
   CF_REQUIRE(a->out && a->residual && a->act == CF_ACT_RELU && a->stride == 1,
              "cf_conv3x3_root_f16x3: conv2 needs its output buffer (fallback), a residual and ReLU");
-  CF_REQUIRE(r->n_src == 2 && r->src[0] == a->out && r->src[1] == a->residual && r->src_c[0] == a->out_stride &&
-                 r->src_c[1] == a->res_stride,
-             "cf_conv3x3_root_f16x3: the Root's sources must be (conv2's output, conv2's residual)");
+  CF_REQUIRE(r->n_src >= 2 && r->n_src <= CF_MAX_SRC && r->src[0] == a->out && r->src[1] == a->residual &&
+                 r->src_c[0] == a->out_stride && r->src_c[1] == a->res_stride,
+             "cf_conv3x3_root_f16x3: the Root's first sources must be (conv2's output, conv2's residual)");
   CF_REQUIRE(r->B == a->B && r->H == a->Ho && r->W == a->Wo && r->Ho == r->H && r->Wo == r->W && r->stride == 1,
              "cf_conv3x3_root_f16x3: the Root is a 1x1 convolution on conv2's output map");
   CF_REQUIRE(r->weight && r->bias && r->out && !r->residual && r->out_scale > 0.0f &&
                  (r->act == CF_ACT_NONE || r->act == CF_ACT_RELU) && r->out_layout == CF_LAYOUT_NHWC &&
                  r->out_stride >= r->N && r->out_stride % 4 == 0,
              "cf_conv3x3_root_f16x3: bad Root argument block");
+  int k_sum = 0;
+  bool pieces_ok = root_channels[0] == a->N && root_channels[1] == a->N;
+  for (int i = 0; i < r->n_src; ++i) {
+    CF_REQUIRE(r->src[i] && root_channels[i] > 0 && root_channels[i] <= r->src_c[i], "cf_conv3x3_root_f16x3: source %d invalid", i);
+    k_sum += root_channels[i];
+    if (i >= 2) pieces_ok = pieces_ok && root_channels[i] % 64 == 0 && r->src_c[i] % 4 == 0;
+  }
+  CF_REQUIRE(k_sum <= r->K_pad, "cf_conv3x3_root_f16x3: the sources' channels (%d) exceed K_pad = %d", k_sum, r->K_pad);
   bool fused = false;
   const bool fusable = (a->N == 64 || a->N == 128 || a->N == 256) && a->N_pad == a->N && r->N == a->N &&
-                       r->N_pad == a->N && r->K_pad == 2 * a->N && a->res_stride % 4 == 0 && r->out_stride % 4 == 0;
-  static const int fuse_on = [] { const char* e = getenv("CF_ROOT_FUSE"); return e ? atoi(e) : 1; }();   // (dev A/B)
-  const int rc = conv3x3_impl(a, (fusable && fuse_on) ? r : nullptr, &fused, stream);
+                       r->N_pad == a->N && pieces_ok && r->K_pad == k_sum && a->res_stride % 4 == 0 && r->out_stride % 4 == 0;
+  static const int fuse_on = [] { const char* e = getenv("CF_ROOT_FUSE"); return e ? atoi(e) : 1; }();   // (dev A/B: 0 off, 1 on, 2 on without children)
+  const bool want = fusable && fuse_on && (fuse_on == 1 || r->n_src == 2);
+  const int rc = conv3x3_impl(a, want ? r : nullptr, root_channels, &fused, stream);
   if (rc != CF_OK || fused) return rc;
   return cf_conv2d_f16x3(r, stream);
 }
-

@@ -326,24 +326,26 @@ class _Plan:
             if levels == 1:
                 x1 = block(p + ".tree1", x, residual)
                 pc2, pcr = pk[p + ".tree2.conv2"], pk[p + ".root"]
-                if (model.root_fuse and model.conv_patch and not children and pc2.out_scale > 0 and pcr.out_scale > 0
+                if (model.root_fuse and model.conv_patch and pc2.out_scale > 0 and pcr.out_scale > 0
                         and getattr(pc2, "patch", False) and pc2.stride == 1):
                     # tree2.conv2 and the Root as ONE step (cf_conv3x3_root_f16x3): x2 is never written where a workgroup
-                    # holds every channel of its pixels (the 64-channel level 2); the library runs the two launches for
-                    # every other shape, bit-identical either way
+                    # holds every channel of its pixels (64 / 128 / 256 channels: levels 2-4; children are read from HBM
+                    # inside the launch); the library runs the two launches for every other shape, bit-identical either way
                     _, h, w, _ = x1.shape
                     t, _ = conv(p + ".tree2.conv1", [x1], h, w)
                     x2, o = buf(B, h, w, pc2.n), buf(B, h, w, pcr.n)
                     a2 = ops.conv_args(pc2, [t], [t.shape[-1]], B, h, w, x2, pc2.n, ACT_RELU, x1, x1.shape[-1],
                                        LAYOUT_NHWC, None, 0, False)
-                    ar = ops.conv_args(pcr, [x2, x1], [pc2.n, x1.shape[-1]], B, h, w, o, pcr.n, ACT_RELU, None, 0,
+                    rsrcs = [x2, x1, *children]
+                    ar = ops.conv_args(pcr, rsrcs, [s_.shape[-1] for s_ in rsrcs], B, h, w, o, pcr.n, ACT_RELU, None, 0,
                                        LAYOUT_NHWC, None, 0, False)
-                    self.keep += [a2, ar]
+                    rch = (C.c_int32 * len(rsrcs))(*[int(c) for c in pcr.real_cin])
+                    self.keep += [a2, ar, rch]
                     name = p + ".tree2.conv2+root"
                     self.step_index[name] = len(self.steps)
                     self.step_flops[name] = 2.0 * B * h * w * (pc2.n * 9 * sum(int(c) for c in pc2.real_cin)
                                                                + pcr.n * sum(int(c) for c in pcr.real_cin))
-                    self.add_step((self.lib.cf_conv3x3_root_f16x3, C.byref(a2), C.byref(ar)))
+                    self.add_step((self.lib.cf_conv3x3_root_f16x3, C.byref(a2), C.byref(ar), rch))
                     return o
                 x2 = block(p + ".tree2", x1, None)
                 _, h, w, _ = x2.shape

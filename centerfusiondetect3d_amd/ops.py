@@ -67,17 +67,19 @@ def conv2d_f16x3(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, residual=None, out
     return out
 
 
-def conv3x3_root_f16x3(pc2: PackedConv, pc_root: PackedConv, t, x1, act_root=ACT_RELU, x2_out=None):
-    """One-level Tree tail: x2 = ReLU(conv3x3(t) + x1), out = act(Root([x2, x1])) as ONE launch where the shape allows
-    (cf_conv3x3_root_f16x3), the two launches otherwise - same bits.  -> (out, x2 buffer: written only on the fallback)."""
-    _need_cuda(t, x1)
+def conv3x3_root_f16x3(pc2: PackedConv, pc_root: PackedConv, t, x1, children=(), act_root=ACT_RELU, x2_out=None):
+    """One-level Tree tail: x2 = ReLU(conv3x3(t) + x1), out = act(Root([x2, x1, *children])) as ONE launch where the shape
+    allows (cf_conv3x3_root_f16x3), the two launches otherwise - same bits.  -> (out, x2 buffer: written only on the fallback)."""
+    _need_cuda(t, x1, *children)
     B, H, W, _ = t.shape
     x2 = torch.empty((B, H, W, pc2.n), device=t.device, dtype=torch.float32) if x2_out is None else x2_out
     out = torch.empty((B, H, W, pc_root.n), device=t.device, dtype=torch.float32)
     a = conv_args(pc2, [t], [t.shape[-1]], B, H, W, x2, x2.shape[-1], ACT_RELU, x1, x1.shape[-1], LAYOUT_NHWC, None, 0, False)
-    r = conv_args(pc_root, [x2, x1], [x2.shape[-1], x1.shape[-1]], B, H, W, out, out.shape[-1], act_root, None, 0,
+    srcs = [x2, x1, *children]
+    r = conv_args(pc_root, srcs, [s.shape[-1] for s in srcs], B, H, W, out, out.shape[-1], act_root, None, 0,
                   LAYOUT_NHWC, None, 0, False)
-    _lib.check(_lib.load().cf_conv3x3_root_f16x3(C.byref(a), C.byref(r), _lib.stream_ptr()), "cf_conv3x3_root_f16x3")
+    ch = (C.c_int32 * len(srcs))(*[int(c) for c in pc_root.real_cin])
+    _lib.check(_lib.load().cf_conv3x3_root_f16x3(C.byref(a), C.byref(r), ch, _lib.stream_ptr()), "cf_conv3x3_root_f16x3")
     return out, x2
 
 

@@ -129,14 +129,15 @@ int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream);
  * input columns as two planes of the LDS patch; same packing, same result as cf_conv2d_f16x3. */
 
 /* cf_conv3x3_root_f16x3: BasicBlock.conv2 (+ residual + ReLU; dla.py:33-41) of a one-level Tree's tree2 and the Tree's
- * Root (1x1 convolution + BN + ReLU over cat(x2, x1); dla.py:105-118, 81-96 with children = []) in ONE launch:
+ * Root (1x1 convolution + BN + ReLU over cat(x2, x1, *children); dla.py:105-118, 81-96) in ONE launch:
  *   x2 = ReLU(conv3x3(t, W2) + b2 + x1);  out = act(W_root . [x2; x1] + b_root)
  * `conv` is conv2's argument block as for cf_conv3x3_f16x3 (residual = x1, act = RELU; `out` = a buffer for x2, written
  * only when the call falls back); `root` is the Root's block as for cf_conv2d_f16x3 with src[0] = conv->out,
- * src[1] = conv->residual.  Where a workgroup holds every channel of its pixels (64 / 128 / 256-channel layers) x2 never leaves the
+ * src[1] = conv->residual and, behind them, the Tree's children (dla.py:109-117; level_root's pooled input, earlier
+ * tree outputs); `root_channels[i]` (host array, n_src entries) = the channels the Root reads from source i.  Where a workgroup holds every channel of its pixels (64 / 128 / 256-channel layers) x2 never leaves the
  * chip: it is split to fp16 hi / lo into LDS as the B operand of the Root's GEMM, whose products and order are those of
  * cf_conv2d_f16x3 - so the result equals the two launches bit for bit, which is what runs for every other shape. */
-int cf_conv3x3_root_f16x3(const cf_conv_args* conv, const cf_conv_args* root, void* stream);
+int cf_conv3x3_root_f16x3(const cf_conv_args* conv, const cf_conv_args* root, const int32_t* root_channels, void* stream);
 
 /* cf_split_bf16: fp32 NHWC [M][in_stride] (C used) -> split-bf16 [M][2][Cs], channels C..Cs-1 zero. */
 int cf_split_bf16(const float* x, void* out, long M, int C, int in_stride, int Cs, void* stream);

@@ -679,37 +679,44 @@ def test_conv3x3_f16x3_stride2_patch(dev, B, Ci, Co, H, W):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("C_,B,H,W,fused", [
-    (64, 2, 112, 200, True),       # level 2 at the bench size: 16 x 16 tiles of one image
-    (64, 24, 37, 41, True),        # flat 256-pixel runs, ragged last run, image borders inside a run
-    (64, 2, 128, 160, True),       # tiled, last tile column / row partly outside
-    (64, 1, 5, 300, False),        # too wide for the LDS patch: the library runs the two launches
-    (64, 1, 28, 50, False),        # a launch small enough for the one-round half tiles: two launches
-    (128, 8, 56, 100, True),       # level3.tree1: two waves per pixel group exchange their 64-channel pieces
-    (128, 2, 112, 200, True),      # ... tiled form (level 3 of a high-resolution input)
-    (128, 12, 37, 41, True),       # ... ragged
-    (256, 8, 28, 50, True),        # level4.tree1: four waves per pixel group
-    (256, 16, 31, 23, True),
-    (256, 1, 14, 25, False),       # small map: K-split tiles, two launches
+@pytest.mark.parametrize("C_,B,H,W,kids,fused", [
+    (64, 2, 112, 200, (), True),        # level 2 at the bench size: 16 x 16 tiles of one image
+    (64, 24, 37, 41, (), True),         # flat 256-pixel runs, ragged last run, image borders inside a run
+    (64, 2, 128, 160, (), True),        # tiled, last tile column / row partly outside
+    (64, 1, 5, 300, (), False),         # too wide for the LDS patch: the library runs the two launches
+    (64, 1, 28, 50, (), False),         # a launch small enough for the one-round half tiles: two launches
+    (128, 8, 56, 100, (), True),        # level3.tree1: two waves per pixel group exchange their 64-channel pieces
+    (128, 2, 112, 200, (), True),       # ... tiled form (level 3 of a high-resolution input)
+    (128, 12, 37, 41, (), True),        # ... ragged
+    (256, 8, 28, 50, (), True),         # level4.tree1: four waves per pixel group
+    (256, 16, 31, 23, (), True),
+    (256, 1, 14, 25, (), False),        # small map: K-split tiles, two launches
+    (128, 8, 56, 100, (64, 128), True),     # level3.tree2: children = [pooled level-2 map, tree1's output], K = 448
+    (256, 8, 28, 50, (128, 256), True),     # level4.tree2: K = 896, six 64-channel pieces in two rounds
+    (64, 2, 112, 200, (64,), True),         # one child, one wave per pixel group
+    (128, 12, 37, 41, (192,), True),        # three pieces for two waves: a round with one piece
+    (128, 8, 56, 100, (32,), False),        # a child that is not a multiple of 64 channels: two launches
 ])
-def test_conv3x3_root_fused_equals_two_launches(dev, C_, B, H, W, fused):
-    """cf_conv3x3_root_f16x3: tree2.conv2 (+ x1, ReLU) and the Tree's Root over (x2, x1) in one launch - the same bits as
-    cf_conv3x3_f16x3 followed by cf_conv2d_f16x3 on the same packed weights, x2 not written when fused, and fp32-level
-    accuracy against float64."""
+def test_conv3x3_root_fused_equals_two_launches(dev, C_, B, H, W, kids, fused):
+    """cf_conv3x3_root_f16x3: tree2.conv2 (+ x1, ReLU) and the Tree's Root over (x2, x1, *children) in one launch - the same
+    bits as cf_conv3x3_f16x3 followed by cf_conv2d_f16x3 on the same packed weights, x2 not written when fused, and
+    fp32-level accuracy against float64."""
     from centerfusiondetect3d_amd import ops, packing
     t, x1 = F.relu(rnd(B, C_, H, W, seed=1)) * 2, F.relu(rnd(B, C_, H, W, seed=2)) * 2
+    ch = [F.relu(rnd(B, c, H, W, seed=10 + i)) * 2 for i, c in enumerate(kids)]
+    K = 2 * C_ + sum(kids)
     w2, b2 = rnd(C_, C_, 3, 3, seed=3, scale=(C_ * 9) ** -0.5), rnd(C_, seed=4)
-    wr, br = rnd(C_, 2 * C_, 1, 1, seed=5, scale=(2 * C_) ** -0.5), rnd(C_, seed=6)
+    wr, br = rnd(C_, K, 1, 1, seed=5, scale=K ** -0.5), rnd(C_, seed=6)
     x2_ref = F.relu(F.conv2d(t.double(), w2.double(), b2.double(), 1, 1) + x1.double())
-    ref = F.relu(F.conv2d(torch.cat([x2_ref, x1.double()], 1), wr.double(), br.double()))
+    ref = F.relu(F.conv2d(torch.cat([x2_ref, x1.double()] + [c.double() for c in ch], 1), wr.double(), br.double()))
     pc2 = packing.pack_conv_f16(w2, b2, [packing.Source(C_, C_)]).to(dev)
-    pcr = packing.pack_conv_f16(wr, br, [packing.Source(C_, C_), packing.Source(C_, C_)]).to(dev)
-    assert pc2.patch and pcr.k_pad == 2 * C_
-    td, x1d = nhwc(t).to(dev), nhwc(x1).to(dev)
+    pcr = packing.pack_conv_f16(wr, br, [packing.Source(C_, C_), packing.Source(C_, C_)] + [packing.Source(c, c) for c in kids]).to(dev)
+    assert pc2.patch and pcr.k_pad == K
+    td, x1d, chd = nhwc(t).to(dev), nhwc(x1).to(dev), [nhwc(c).to(dev) for c in ch]
     x2_buf = torch.full((B, H, W, C_), float("nan"), device=dev)
-    out, _ = ops.conv3x3_root_f16x3(pc2, pcr, td, x1d, x2_out=x2_buf)
+    out, _ = ops.conv3x3_root_f16x3(pc2, pcr, td, x1d, chd, x2_out=x2_buf)
     x2_two = ops.conv2d_f16x3(pc2, [td], B, H, W, act=1, residual=x1d)
-    out_two = ops.conv2d_f16x3(pcr, [x2_two, x1d], B, H, W, act=1)
+    out_two = ops.conv2d_f16x3(pcr, [x2_two, x1d, *chd], B, H, W, act=1)
     assert torch.equal(out, out_two)
     if fused:
         assert torch.isnan(x2_buf).all()                 # x2 never left the chip
