@@ -115,3 +115,15 @@ def test_integration_md_shows_the_real_dcn_args():
     assert [(n, t) for n, t in doc._fields_] == [(n, t) for n, t in _lib.DcnArgs._fields_]
     assert C.sizeof(doc) == C.sizeof(_lib.DcnArgs)
     assert f"CF_ABI_VERSION {_lib.ABI_VERSION}" in m.group(0)
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check (`__graft_entry__.build()`): incremental compile, dlopen, every header symbol resolved and
+    the ABI version the binding was written against (it carried a stale literal once)."""
+    import importlib, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        importlib.import_module("__graft_entry__").build()
+    finally:
+        sys.path.remove(root)
