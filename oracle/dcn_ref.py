@@ -5,7 +5,8 @@ third-party op on the reference hot path (call site
 /root/reference/src/lib/model/networks/dla.py:461-470).  torchvision is NOT in
 /root/reference nor in this image and the reference does not pin its version
 (requirements.txt:1-12), so this restatement is PARITY UNPINNED against the
-real op; it is held by the known-answer tests in tests/test_oracle_dcn.py
+real op; it is held by the known-answer tests in tests/test_oracle_dcn.py - and cross-checked there against an
+independent formulation on torch's own F.grid_sample (float64, random offsets on and beyond every border) -
 (zero offset == conv2d, integer offset == shifted conv, mask linearity,
 all-out-of-range == bias, half-pixel == mean of neighbours).
 

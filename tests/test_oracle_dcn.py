@@ -90,3 +90,35 @@ def test_border_rule_minus_one_exclusive():
     off[:, 8] = -1.0
     out = deform_conv2d(x, off, w, None, (1, 1), (1, 1), (1, 1), None)
     assert torch.all(out[0, 0, 0] == 0) and torch.all(out[0, 0, 1:] == 1)
+
+
+def test_random_offsets_equal_an_independent_grid_sample_formulation():
+    """Cross-check of the restated bilinear core against a DIFFERENT implementation of the same published semantics:
+    torch's own `F.grid_sample(mode="bilinear", padding_mode="zeros", align_corners=True)` samples each tap's positions
+    (a corner outside the image contributes zero; everything beyond (-1, H) x (-1, W) is zero - torchvision's rule), the
+    mask and the weight contraction are applied with einsum.  Random fractional offsets of several pixels, positions on
+    and beyond every border, float64: the two agree to rounding.  torchvision itself is absent, so this is
+    the strongest pin available for `deform_conv2d`'s arithmetic."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    B, C, Co, H, W = 2, 8, 5, 13, 17
+    x = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
+    off = torch.randn(B, 18, H, W, generator=g, dtype=torch.float64) * 3.0
+    off[:, :, 0, :] -= 2.5                                   # rows / columns that sample above / left of / beyond the image
+    off[:, :, :, -1] += 2.5
+    off[0, :, 5, 5] = torch.tensor([-6.0, -6.0] * 9, dtype=torch.float64)       # far outside
+    off[1, 0::2, 7, 3] = -0.5                                # exactly half a pixel
+    mask = torch.rand(B, 9, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Co, C, 3, 3, generator=g, dtype=torch.float64)
+    b = torch.randn(Co, generator=g, dtype=torch.float64)
+    ref = deform_conv2d(x, off, w, b, (1, 1), (1, 1), (1, 1), mask)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    out = b.view(1, Co, 1, 1).expand(B, Co, H, W).clone()
+    for k in range(9):
+        i, j = divmod(k, 3)
+        py = ys - 1 + i + off[:, 2 * k]                      # (B,H,W): channel 2k = dy, 2k+1 = dx of tap k = 3i + j
+        px = xs - 1 + j + off[:, 2 * k + 1]
+        grid = torch.stack([2 * px / (W - 1) - 1, 2 * py / (H - 1) - 1], dim=-1)
+        s = F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=True)     # (B,C,H,W)
+        out += torch.einsum("oc,bchw->bohw", w[:, :, i, j], s * mask[:, k:k + 1])
+    assert float((out - ref).abs().max()) < 1e-11 * float(ref.abs().max() + 1)
