@@ -51,3 +51,37 @@ def test_normalisation_is_float64_then_cast():
     out = pp.pre_process_images([im], [[1, 0, 0], [0, 1, 0]], (8, 8), mean, std)
     ref = ((im / 255.0 - mean) / std).astype(np.float32).transpose(2, 0, 1)[None]
     assert out.dtype == np.float32 and np.array_equal(out, ref)
+
+
+def test_general_affine_agrees_with_an_independent_float_bilinear_warp():
+    """Geometry cross-check against a DIFFERENT implementation: torch's `F.grid_sample` (float bilinear, zero padding,
+    pixel-centre coordinates) warps the same smooth frame through the same forward matrix - a rotation + anisotropic scale
+    + shift that no known-answer case covers.  OpenCV's arithmetic quantises the source position to 1/32 pixel and the
+    weights to 15 bits, so on a smooth image (gradient <= 2 levels per pixel) the two must agree within one grey level
+    wherever all four taps lie inside the frame, and within 255 / 32 + 1 levels where a tap reads the zero border (the
+    1/32-pixel position step times the jump at the edge): direction of the map, inversion, tap order and border handling
+    are all exercised."""
+    import torch
+    import torch.nn.functional as F
+    Hs, Ws, Hd, Wd = 60, 90, 50, 70
+    yy, xx = np.mgrid[0:Hs, 0:Ws].astype(np.float64)
+    img = np.stack([100 + 60 * np.sin(xx / 9.0) + 50 * np.cos(yy / 7.0), 20 + 1.9 * xx + 0.5 * yy,
+                    128 + 100 * np.sin((xx + yy) / 11.0)], axis=-1)
+    img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    th = np.deg2rad(17.0)
+    M = np.array([[0.8 * np.cos(th), -0.9 * np.sin(th), 6.3], [0.8 * np.sin(th), 0.9 * np.cos(th), -4.7]])
+    got = pp.warp_affine_u8(img, M, (Wd, Hd)).astype(np.float64)
+    A = np.vstack([M, [0, 0, 1]])
+    Ai = np.linalg.inv(A)                                                # dst -> src, plain float64 linear algebra
+    yd, xd = np.mgrid[0:Hd, 0:Wd].astype(np.float64)
+    sx = Ai[0, 0] * xd + Ai[0, 1] * yd + Ai[0, 2]
+    sy = Ai[1, 0] * xd + Ai[1, 1] * yd + Ai[1, 2]
+    grid = torch.from_numpy(np.stack([2 * sx / (Ws - 1) - 1, 2 * sy / (Hs - 1) - 1], -1))[None]
+    src = torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None]
+    ref = F.grid_sample(src, grid, mode="bilinear", padding_mode="zeros", align_corners=True)[0].permute(1, 2, 0).numpy()
+    inside = (sx >= 0) & (sx <= Ws - 1) & (sy >= 0) & (sy <= Hs - 1)
+    err = np.abs(got - ref).max(-1)
+    assert float(err[inside].max()) <= 1.0 + 1e-9, float(err[inside].max())
+    assert float(err.max()) <= 255.0 / 32 + 1.0, float(err.max())
+    assert int(inside.sum()) > 1500 and int((~inside).sum()) > 300
+    assert int((ref == 0).all(-1).sum()) > 50 and int((ref > 0).all(-1).sum()) > 1000      # borders AND interior present
