@@ -721,7 +721,7 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const i
   const bool s2 = a->stride == 2;
   CF_REQUIRE((a->stride == 1 && a->Ho == a->H && a->Wo == a->W) ||
              (s2 && a->Ho == (a->H - 1) / 2 + 1 && a->Wo == (a->W - 1) / 2 + 1), "cf_conv3x3_f16x3: 3x3, pad 1, stride 1 or 2");
-  CF_REQUIRE(!s2 || !a->residual, "cf_conv3x3_f16x3: no residual on the stride-2 form");
+  if (s2 && a->residual) return cf_conv2d_f16x3(a, stream);   // (the stride-2 tile has no residual epilogue: same weights, slot kernel)
   CF_REQUIRE(a->K_pad > 0 && a->K_pad % 32 == 0, "cf_conv3x3_f16x3: K_pad=%d not a multiple of 32", a->K_pad);
   CF_REQUIRE(a->N > 0 && a->N_pad >= a->N && (a->N_pad == 32 || a->N_pad % 64 == 0), "cf_conv3x3_f16x3: N=%d N_pad=%d", a->N, a->N_pad);
   CF_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0, "cf_conv3x3_f16x3: bad geometry");

@@ -679,6 +679,19 @@ def test_conv3x3_f16x3_stride2_patch(dev, B, Ci, Co, H, W):
     assert torch.equal(out, out2)
 
 
+def test_conv3x3_f16x3_stride2_with_residual_runs_the_slot_kernel(dev):
+    """The stride-2 tile has no residual epilogue: such a call is forwarded to the slot kernel (same weights), not refused."""
+    from centerfusiondetect3d_amd import ops, packing
+    B, Ci, Co, H, W = 2, 32, 64, 30, 44
+    x, w, b = rnd(B, Ci, H, W, seed=1), rnd(Co, Ci, 3, 3, seed=2, scale=(Ci * 9) ** -0.5), rnd(Co, seed=3)
+    r = rnd(B, Co, 15, 22, seed=4)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), 2, 1) + r.double())
+    pc = packing.pack_conv_f16(w, b, [packing.Source(Ci, Ci)], stride=2).to(dev)
+    out = ops.conv2d_f16x3(pc, [nhwc(x).to(dev)], B, H, W, act=1, residual=nhwc(r).to(dev), patch=True)
+    err = float((nchw(out).cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 1.5e-6, err
+
+
 @pytest.mark.parametrize("C_,B,H,W,kids,fused", [
     (64, 2, 112, 200, (), True),        # level 2 at the bench size: 16 x 16 tiles of one image
     (64, 24, 37, 41, (), True),         # flat 256-pixel runs, ragged last run, image borders inside a run
