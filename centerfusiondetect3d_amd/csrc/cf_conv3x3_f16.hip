@@ -771,10 +771,15 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const i
       kr.root_xsrc_ch[i] = i + 2 < root->n_src ? root_ch[i + 2] : 0;
     }
     const bool t2r = (long)a->H * a->W >= 4096 && tiles_fit(a->H, a->W);
-    // (launches small enough for the one-round half tiles below keep those and the two launches: same bits)
     const long half_tiles = (long)((a->H + 7) / 8) * ((a->W + 15) / 16) * B;
     bool okr = false;
-    if (a->N_pad == 64 && half_tiles > 256)
+    // small launches (latency chains of bs = 1 ... 4): the half-height tiles of the unfused path, fused - one launch less
+    // where the whole chain is a handful of under-filled launches
+    if (a->N_pad == 64 && half_tiles <= 256)
+      okr = try_launch<1, 4, 1, 2, 4, true, 2, true, 1, false, true>(kr, B, st);
+    else if (a->N_pad == 256 && (long)a->H * a->W > 512 && (M + 31) / 32 <= 256)
+      okr = try_launch<4, 1, 1, 2, 4, true, 2, false, 1, false, true>(kr, B, st);
+    else if (a->N_pad == 64 && half_tiles > 256)
       okr = (t2r && try_launch<1, 4, 1, 2, 6, true, 2, true, 2, false, true>(kr, B, st)) ||
             try_launch<1, 4, 1, 2, 6, true, 2, false, 2, false, true>(kr, B, st);
     else if (a->N_pad == 128 && 2 * half_tiles > 256)

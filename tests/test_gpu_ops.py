@@ -696,8 +696,12 @@ def test_conv3x3_f16x3_stride2_with_residual_runs_the_slot_kernel(dev):
     (64, 2, 112, 200, (), True),        # level 2 at the bench size: 16 x 16 tiles of one image
     (64, 24, 37, 41, (), True),         # flat 256-pixel runs, ragged last run, image borders inside a run
     (64, 2, 128, 160, (), True),        # tiled, last tile column / row partly outside
-    (64, 1, 5, 300, (), False),         # too wide for the LDS patch: the library runs the two launches
-    (64, 1, 28, 50, (), False),         # a launch small enough for the one-round half tiles: two launches
+    (64, 20, 5, 300, (), False),        # too wide for the flat LDS patch, too small a map for the tiled one: two launches
+    (64, 1, 5, 300, (), True),          # ... the same map in a small launch: half tiles (8 x 16), fused
+    (64, 1, 28, 50, (), True),          # a launch small enough for the one-round half tiles: those, fused
+    (64, 1, 112, 200, (), True),        # ... level 2 of ONE frame (175 half tiles)
+    (256, 1, 28, 50, (128, 256), True), # ... level4.tree2 of one frame, with children
+    (128, 1, 56, 100, (), False),       # ... 128 channels: the half tiles hold 64 channels per workgroup - two launches
     (128, 8, 56, 100, (), True),        # level3.tree1: two waves per pixel group exchange their 64-channel pieces
     (128, 2, 112, 200, (), True),       # ... tiled form (level 3 of a high-resolution input)
     (128, 12, 37, 41, (), True),        # ... ragged
