@@ -300,10 +300,17 @@ class _Plan:
             self.add_step((fn, C.byref(a)))
             return out, a
 
+        pooled = {}
+
         def pool(x):
+            # (a two-level Tree pools its input for its own Root AND its first sub-tree pools the same tensor again,
+            #  dla.py:96,107 at both nesting levels: one launch serves both)
+            if x.data_ptr() in pooled:
+                return pooled[x.data_ptr()]
             _, h, w, c = x.shape
             o = buf(B, h // 2, w // 2, c)
             self.add_step((self.lib.cf_maxpool2x2, x.data_ptr(), o.data_ptr(), B, h, w, c))
+            pooled[x.data_ptr()] = o
             return o
 
         def block(p, x, residual):
