@@ -363,13 +363,15 @@ class StepClock:
     """Per-rank diagnostics of the timed steps, so that an N>1 line explains itself (8 Python launch threads share one
     host; a bad scaling figure must be attributable to host enqueue, to the exchange, or to neither):
       host_enqueue_ms  perf_counter around ONE step's launches - forward, decode + postProcess, all-gather submit -
-                       before any wait: the host-side cost of keeping the GPU fed;
+                       before any wait; the MINIMUM over the timed steps = what the host needs when nothing blocks it.
+                       host_enqueue_mean_ms is the mean: once the host runs a queue's depth ahead of the GPU its launches
+                       block, so the mean tends to the GPU's step time - host-bound is min ~ mean ~ step_ms;
       gather_wait_ms   time the compute stream spends blocked on the previous step's all-gather (HIP events either side
                        of `work.wait()`, which orders the stream and does not block the host); on CPU (gloo rehearsal) the
                        host time of the blocking wait;
       step_ms          this rank's own wall time per step (the headline uses the MAX over ranks).
     Rank 0 prints every rank's figures as `ranks: [...]`."""
-    FIELDS = ("step_ms", "host_enqueue_ms", "gather_wait_ms", "gather_wait_host_ms")
+    FIELDS = ("step_ms", "host_enqueue_ms", "host_enqueue_mean_ms", "gather_wait_ms", "gather_wait_host_ms")
 
     def __init__(self, device):
         self.cuda = device is not None and torch.device(device).type == "cuda"
@@ -398,10 +400,12 @@ class StepClock:
         return out
 
     def row(self, dt, steps):
-        """-> [step_ms, host_enqueue_ms, gather_wait_ms, gather_wait_host_ms] of this rank (call after a device sync)."""
+        """-> [step_ms, host_enqueue_ms (min), host_enqueue_mean_ms, gather_wait_ms, gather_wait_host_ms] of this rank
+        (call after a device sync)."""
         wh = 1e3 * float(np.mean(self.wait_host)) if self.wait_host else 0.0
         wd = float(np.mean([a.elapsed_time(b) for a, b in self.wait_ev])) if self.wait_ev else (0.0 if self.cuda else wh)
-        return [dt / steps * 1e3, 1e3 * float(np.mean(self.enq)) if self.enq else 0.0, wd, wh]
+        return [dt / steps * 1e3, 1e3 * float(np.min(self.enq)) if self.enq else 0.0,
+                1e3 * float(np.mean(self.enq)) if self.enq else 0.0, wd, wh]
 
     @staticmethod
     def gather_rows(row, world, device):
@@ -527,6 +531,10 @@ def main():
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="no GPU, no measurement: run this file's multi-rank control flow over gloo with a stand-in forward "
                          "(tests; the JSON line is marked as a rehearsal)")
+    ap.add_argument("--use-graph", action="store_true",
+                    help="model.use_graph: replay the forward as ONE captured HIP graph - the host then issues one launch per "
+                         "step instead of ~165 (diagnosis of an N > 1 run whose ranks' host_enqueue_ms says the host is the "
+                         "bottleneck; on one GPU eager launches are as fast: DESIGN.md section 3)")
     ap.add_argument("--end-to-end", action="store_true",
                     help="print the Detector.run-shaped line instead (uint8 frames + raw radar over PCIe -> final boxes)")
     args = ap.parse_args()
@@ -580,6 +588,7 @@ def main():
         model.heads_bf16 = False
     model = synthetic_weights(model, seed=0, offset_std=args.offset_std).to(dev).eval()
     model.streams = max(1, args.streams)
+    model.use_graph = bool(args.use_graph)
     if args.end_to_end:
         if rank == 0:
             os.write(json_fd, (json.dumps(end_to_end(args, dev, model)) + "\n").encode())
@@ -632,6 +641,19 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         clock.on = False
+    if args.use_graph:
+        # a graph replay has no per-launch events: the dominant kernel is timed in three eager steps behind the timed region
+        model.use_graph = False
+        with torch.no_grad():
+            step()
+            drain()
+            for name in dominant:
+                model.time_launch(name, True)
+            for _ in range(3):
+                step()
+            drain()
+        torch.cuda.synchronize()
+        model.use_graph = True
     launch_ms, launch_flops = [], 0.0
     for name in dominant:
         ms, fl = model.launch_times(name)

@@ -50,9 +50,9 @@ def test_multi_rank_control_flow_rehearsal_bare_spawn():
     # every rank's own diagnostics (bench.StepClock): step time, host time to enqueue one step, wait on the exchange
     assert [r["rank"] for r in d["ranks"]] == [0, 1]
     for r in d["ranks"]:
-        assert set(r) == {"rank", "step_ms", "host_enqueue_ms", "gather_wait_ms", "gather_wait_host_ms"}
-        assert r["step_ms"] > 0 and r["host_enqueue_ms"] > 0 and r["gather_wait_ms"] >= 0
-        assert r["host_enqueue_ms"] + r["gather_wait_host_ms"] <= r["step_ms"] * 1.5
+        assert set(r) == {"rank", "step_ms", "host_enqueue_ms", "host_enqueue_mean_ms", "gather_wait_ms", "gather_wait_host_ms"}
+        assert r["step_ms"] > 0 and 0 < r["host_enqueue_ms"] <= r["host_enqueue_mean_ms"] and r["gather_wait_ms"] >= 0
+        assert r["host_enqueue_mean_ms"] + r["gather_wait_host_ms"] <= r["step_ms"] * 1.5
     assert d["ms_per_step"] >= max(r["step_ms"] for r in d["ranks"]) - 1e-3        # the headline is the MAX over ranks
 
 
