@@ -1,6 +1,7 @@
 // HBM-bound helpers of the DLA-34 / IDA-up graph: depthwise transposed-conv upsample (+ skip add),
 // 2x2 max-pool and the two layout changes at the module boundary.  All are one-pass streaming
 // kernels: 16 B per lane, channel-innermost (NHWC) so every wave-instruction touches whole lines.
+#include <stdlib.h>
 #include "cf_common.h"
 
 namespace {
@@ -42,6 +43,75 @@ __global__ __launch_bounds__(256) void upsample_dw_kernel(const float* __restric
       }
     }
     reinterpret_cast<f32x4*>(out)[row_base + j] = acc;
+  }
+}
+
+// f = 2 (every upsample of the neck but one): a thread owns a 2 x 2 OUTPUT block of 4 channels.  The per-pixel kernel
+// above issues 4 input + 4 weight + 1 skip load per output value group - each input row is requested 16 times and the
+// vector-memory path, not HBM, sets its pace (207 MB in 50 us = 4.2 TB/s).  A block needs the 3 x 3 input neighbourhood
+// once (9 loads for 16 taps) and the 16 weights once per THREAD (the in-row index advances by a multiple of C4, so a
+// thread keeps its channel group): 17 memory instructions per 4 outputs instead of 40.  Every output is the same sum in
+// the same order as upsample_dw_kernel<2> computes it (taps (ky0, kx0), (ky0, kx0 + 2), (ky0 + 2, kx0), (ky0 + 2, kx0 + 2);
+// taps outside the input skipped): bit-identical.
+__global__ __launch_bounds__(256) void upsample2_block_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ skip, float* __restrict__ out,
+                                                              int H, int W, int C4) {
+  const int i = blockIdx.y, b = blockIdx.z;          // input row
+  const int Wo = 2 * W;
+  const int row_len = W * C4;
+  const int j0 = blockIdx.x * 256 + threadIdx.x;
+  if (j0 >= row_len) return;
+  const int c4 = j0 % C4;
+  f32x4 ww[4][4];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) ww[ky][kx] = reinterpret_cast<const f32x4*>(w)[(ky * 4 + kx) * C4 + c4];
+  const bool up = i >= 1, dn = i + 1 < H;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x) + (size_t)(b * H + i) * W * C4;     // input row i
+  const f32x4* xu = xr - (up ? (size_t)W * C4 : 0);                                       // row i - 1 (or a valid dummy)
+  const f32x4* xd = xr + (dn ? (size_t)W * C4 : 0);                                       // row i + 1
+  const size_t orow0 = ((size_t)b * 2 * H + 2 * i) * Wo * C4, orow1 = orow0 + (size_t)Wo * C4;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (int j = j0; j < row_len; j += gridDim.x * 256) {
+    const int jx = j / C4;
+    const bool lf = jx >= 1, rg = jx + 1 < W;
+    const int cl = (lf ? jx - 1 : jx) * C4 + c4, cc = jx * C4 + c4, cr = (rg ? jx + 1 : jx) * C4 + c4;
+    const f32x4 u0 = xu[cl], u1 = xu[cc], u2 = xu[cr];
+    const f32x4 m0 = xr[cl], m1 = xr[cc], m2 = xr[cr];
+    const f32x4 d0 = xd[cl], d1 = xd[cc], d2 = xd[cr];
+    const size_t o00 = orow0 + (size_t)(2 * jx) * C4 + c4, o10 = orow1 + (size_t)(2 * jx) * C4 + c4;
+    f32x4 a00 = zero, a01 = zero, a10 = zero, a11 = zero;
+    if (skip) {
+      a00 = reinterpret_cast<const f32x4*>(skip)[o00];
+      a01 = reinterpret_cast<const f32x4*>(skip)[o00 + C4];
+      a10 = reinterpret_cast<const f32x4*>(skip)[o10];
+      a11 = reinterpret_cast<const f32x4*>(skip)[o10 + C4];
+    }
+    // output (2i, 2jx): ky in {1, 3} -> rows i, i - 1; kx in {1, 3} -> columns jx, jx - 1
+    a00 += m1 * ww[1][1];
+    if (lf) a00 += m0 * ww[1][3];
+    if (up) a00 += u1 * ww[3][1];
+    if (up && lf) a00 += u0 * ww[3][3];
+    // output (2i, 2jx + 1): kx in {0, 2} -> columns jx + 1, jx
+    if (rg) a01 += m2 * ww[1][0];
+    a01 += m1 * ww[1][2];
+    if (up && rg) a01 += u2 * ww[3][0];
+    if (up) a01 += u1 * ww[3][2];
+    // output (2i + 1, 2jx): ky in {0, 2} -> rows i + 1, i
+    if (dn) a10 += d1 * ww[0][1];
+    if (dn && lf) a10 += d0 * ww[0][3];
+    a10 += m1 * ww[2][1];
+    if (lf) a10 += m0 * ww[2][3];
+    // output (2i + 1, 2jx + 1)
+    if (dn && rg) a11 += d2 * ww[0][0];
+    if (dn) a11 += d1 * ww[0][2];
+    if (rg) a11 += m2 * ww[2][0];
+    a11 += m1 * ww[2][2];
+    reinterpret_cast<f32x4*>(out)[o00] = a00;
+    reinterpret_cast<f32x4*>(out)[o00 + C4] = a01;
+    reinterpret_cast<f32x4*>(out)[o10] = a10;
+    reinterpret_cast<f32x4*>(out)[o10 + C4] = a11;
   }
 }
 
@@ -139,6 +209,14 @@ extern "C" int cf_upsample_dw(const float* x, const float* weight, const float* 
   const int row_len = W * f * (C / 4);
   const dim3 grid((unsigned)((row_len + 255) / 256), (unsigned)(H * f), (unsigned)B);
   hipStream_t st = (hipStream_t)stream;
+  // f = 2 with a channel-group count that divides the workgroup: 2 x 2 output blocks per thread (same sums, same order).
+  // CF_UPSAMPLE_BLOCK=0: dev A/B against the per-pixel kernel.
+  static const int block_on = [] { const char* e = getenv("CF_UPSAMPLE_BLOCK"); return e ? atoi(e) : 1; }();
+  if (f == 2 && block_on && 256 % (C / 4) == 0) {
+    const dim3 g2((unsigned)((W * (C / 4) + 255) / 256), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL(upsample2_block_kernel, g2, dim3(256), 0, st, x, weight, skip, out, H, W, C / 4);
+    return cf_check_launch("cf_upsample_dw");
+  }
   if (f == 2)
     hipLaunchKernelGGL(upsample_dw_kernel<2>, grid, dim3(256), 0, st, x, weight, skip, out, H, W, C / 4, f);
   else if (f == 4)

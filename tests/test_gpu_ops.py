@@ -155,7 +155,7 @@ def test_dcn_known_answers_on_device(dev):
 
 
 # ----------------------------------------------------------------------------------- elementwise
-@pytest.mark.parametrize("f,C,H,W", [(2, 64, 14, 25), (4, 64, 7, 13), (2, 256, 5, 9)])
+@pytest.mark.parametrize("f,C,H,W", [(2, 64, 14, 25), (4, 64, 7, 13), (2, 256, 5, 9), (2, 128, 5, 1), (2, 64, 1, 6), (2, 24, 3, 4)])
 def test_upsample_dw(dev, f, C, H, W):
     from centerfusiondetect3d_amd import ops, packing
     x, w = rnd(2, C, H, W, seed=1), rnd(C, 1, 2 * f, 2 * f, seed=2)
