@@ -370,19 +370,46 @@ class StepClock:
                        of `work.wait()`, which orders the stream and does not block the host); on CPU (gloo rehearsal) the
                        host time of the blocking wait;
       step_ms          this rank's own wall time per step (the headline uses the MAX over ranks).
-    Rank 0 prints every rank's figures as `ranks: [...]`."""
-    FIELDS = ("step_ms", "host_enqueue_ms", "host_enqueue_mean_ms", "gather_wait_ms", "gather_wait_host_ms")
+      step_ms_p50 / _p95 / _max   the distribution of this rank's timed steps: device time between HIP events recorded behind
+                       every step's launches on the compute stream (the headline `value` stays frames / total wall time).
+    Rank 0 prints every rank's figures as `ranks: [...]`; the line's own step_ms_p50 / p95 / max are the MAX over ranks."""
+    FIELDS = ("step_ms", "host_enqueue_ms", "host_enqueue_mean_ms", "gather_wait_ms", "gather_wait_host_ms",
+              "step_ms_p50", "step_ms_p95", "step_ms_max")
 
     def __init__(self, device):
         self.cuda = device is not None and torch.device(device).type == "cuda"
         self.on, self.enq, self.wait_host, self.wait_ev = False, [], [], []
+        self.marks = []          # one stamp per timed step boundary: HIP events on the compute stream (host times on CPU)
+
+    def mark(self):
+        """a step boundary on the compute stream: start() before the first timed step, then behind every step's launches.
+        The distribution of the steps (median, not only a mean) is the differences of consecutive marks -
+        device time, so a host that runs a queue ahead does not blur it."""
+        if self.cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.marks.append(e)
+        else:
+            self.marks.append(time.perf_counter())
+
+    def start(self):
+        self.on = True
+        self.marks = []
+        self.mark()
 
     def enqueue(self, fn):
         t0 = time.perf_counter()
         r = fn()
         if self.on:
             self.enq.append(time.perf_counter() - t0)
+            self.mark()
         return r
+
+    def step_times_ms(self):
+        """device time between consecutive step boundaries (call after a device sync)"""
+        if self.cuda:
+            return [a.elapsed_time(b) for a, b in zip(self.marks[:-1], self.marks[1:])]
+        return [1e3 * (b - a) for a, b in zip(self.marks[:-1], self.marks[1:])]
 
     def wait(self, pending):
         if not self.on:
@@ -404,8 +431,10 @@ class StepClock:
         (call after a device sync)."""
         wh = 1e3 * float(np.mean(self.wait_host)) if self.wait_host else 0.0
         wd = float(np.mean([a.elapsed_time(b) for a, b in self.wait_ev])) if self.wait_ev else (0.0 if self.cuda else wh)
+        st = self.step_times_ms() or [dt / steps * 1e3]
         return [dt / steps * 1e3, 1e3 * float(np.min(self.enq)) if self.enq else 0.0,
-                1e3 * float(np.mean(self.enq)) if self.enq else 0.0, wd, wh]
+                1e3 * float(np.mean(self.enq)) if self.enq else 0.0, wd, wh,
+                float(np.percentile(st, 50)), float(np.percentile(st, 95)), float(np.max(st))]
 
     @staticmethod
     def gather_rows(row, world, device):
@@ -479,7 +508,7 @@ def rehearse(args, world, rank, collective, json_fd):
     drain()
     if world > 1:
         dist.barrier()
-    clock.on = True
+    clock.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -498,6 +527,7 @@ def rehearse(args, world, rank, collective, json_fd):
     if rank == 0:
         os.write(json_fd, (json.dumps({"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": world,
                                        "steps": args.steps, "warmup": args.warmup, "rehearsal": True, "ranks": ranks,
+                                       **{k: max(r[k] for r in ranks) for k in ("step_ms_p50", "step_ms_p95", "step_ms_max")},
                                        "ms_per_step": round(float(t.item()) / args.steps * 1e3, 3), "scaling": "weak",
                                        "config": {"workload": "control-flow rehearsal on CPU (gloo), no forward",
                                                   "global_batch": B * world}}) + "\n").encode())
@@ -525,6 +555,9 @@ def main():
     ap.add_argument("--exact-fp32", action="store_true",
                     help="every product in exact fp32 (fp32 MFMA kernels with two-level summation; conv_f16 / heads_bf16 "
                          "off) instead of the default split-operand products - the accuracy reference build, 3.5x slower")
+    ap.add_argument("--heads-bf16x3", action="store_true",
+                    help="A/B: the heads' first layers on bf16x3 (3 MFMA passes per product, the round-4 arithmetic) instead of "
+                         "fp16 main term + block-scaled FP6 cross terms (1.5 passes; model.heads_mx)")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the RCCL process group and issue the per-step all-gather also at world size 1 (what a "
                          "rank of an N-GPU run does, on a one-GPU box)")
@@ -586,6 +619,8 @@ def main():
     if args.exact_fp32:
         model.conv_f16 = False
         model.heads_bf16 = False
+    if args.heads_bf16x3:
+        model.heads_mx = False
     model = synthetic_weights(model, seed=0, offset_std=args.offset_std).to(dev).eval()
     model.streams = max(1, args.streams)
     model.use_graph = bool(args.use_graph)
@@ -633,7 +668,7 @@ def main():
         for name in dominant:
             model.time_launch(name, True)
         fence()
-        clock.on = True
+        clock.start()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -679,13 +714,17 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32" if args.exact_fp32 else
-                      "f32 storage + f32 accumulate; products as 3 split-operand MFMA passes (f16x3 backbone/neck, bf16x3 heads)"),
+                      "f32 storage + f32 accumulate; products as 3 split-operand MFMA passes (f16x3 backbone/neck, bf16x3 heads)"
+                      if not model._mx_active else
+                      "f32 storage + f32 accumulate; products as split-operand MFMA passes: f16x3 backbone/neck (3 passes), heads' "
+                      "first 3x3 layers fp16 main term + block-scaled FP6 e2m3 cross terms (1.5 passes), heads' 1x1 layers bf16x3"),
             "data": "synthetic",
             "config": {"workload": f"Centerfusion_Middle (DLA-34 + DCNv2 neck + pc_dep frustum fusion, 7+4 heads) "
                                    f"forward + NMS/top-100 decode + 2D->3D postProcess, bs={B}/GPU, 3x{H}x{W}, 50-200 radar pts/frame, "
                                    f"random-init weights",
                        "global_batch": B * world, "parallelism": f"dp{world} (batch shard, async all-gather of the final boxes)"},
             "per_gpu_frames_per_s": round(fps / world, 2),
+            **{k: max(r[k] for r in ranks) for k in ("step_ms_p50", "step_ms_p95", "step_ms_max")},
             "ranks": ranks,
             "model_tflops": round(fps * GFLOP_PER_FRAME * (H * W) / (448 * 800) / 1e3, 2),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
@@ -693,10 +732,15 @@ def main():
                          "traffic": None if args.exact_fp32 else measured_traffic(),
                          "kernel": ("conv_igemm_kernel (fp32 MFMA; the 3x3 first layers of the 7 primary / 4 secondary heads)"
                                     if args.exact_fp32 else
-                                    "head_patch16_kernel (cf_head_fused, v_mfma_f32_16x16x32_bf16; 2 launches/step: 7 primary heads, 4 secondary heads)"),
+                                    "head_patch16_kernel (cf_head_fused, v_mfma_f32_16x16x32_bf16; 2 launches/step: 7 primary heads, 4 secondary heads)"
+                                    if not model._mx_active else
+                                    "head_patch16_kernel<MX> (cf_head_fused mx: v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4 first layer, "
+                                    "v_mfma_f32_16x16x32_bf16 tail layers; 2 launches/step: 7 primary heads, 4 secondary heads)"),
                          "note": ("algorithmic FLOPs (2*MACs) against the fp32 MFMA peak" if args.exact_fp32 else
                                   "algorithmic FLOPs (2*MACs); the kernel issues 3 bf16 MFMA passes per MAC "
-                                  "(split operands), so MFMA-pipe utilisation is 3x frac"),
+                                  "(split operands), so MFMA-pipe utilisation is 3x frac" if not model._mx_active else
+                                  "algorithmic FLOPs (2*MACs) against the dense bf16/f16 MFMA peak; a first-layer MAC costs 1 fp16 pass + "
+                                  "1/2 pass-equivalent of FP6 cross terms (4x rate), a 1x1-layer MAC 3 bf16 passes"),
                          "flop_per_launch": launch_flops, "avg_launch_ms": round(avg_ms, 4),
                          "launches_timed": len(launch_ms)},
         }

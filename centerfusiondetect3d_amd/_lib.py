@@ -6,7 +6,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcfhip.so")
 
-ABI_VERSION = 3      # CF_ABI_VERSION of include/cf_hip.h this binding was written against
+ABI_VERSION = 4      # CF_ABI_VERSION of include/cf_hip.h this binding was written against
 CF_MAX_SRC = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, ACT_RAW_AND_SIGDEPTH = 0, 1, 2, 3
 LAYOUT_NHWC, LAYOUT_NCHW, LAYOUT_NHWC_SPLIT_BF16 = 0, 1, 2
@@ -50,7 +50,7 @@ class HeadFusedArgs(C.Structure):
     _fields_ = [("tail", HeadTailArgs), ("src", _f * 2), ("src_c", C.c_int32 * 2), ("n_src", C.c_int32),
                 ("slots", _f), ("K_pad", C.c_int32), ("w_first", _f * CF_MAX_HEADS),
                 ("b_first", _f * CF_MAX_HEADS), ("layout3x3", C.c_int32), ("w_out_perm", _f * CF_MAX_HEADS),
-                ("mfma16", C.c_int32)]
+                ("mfma16", C.c_int32), ("mx", C.c_int32), ("first_scale", C.c_float * CF_MAX_HEADS)]
 
 
 class StemArgs(C.Structure):
@@ -87,6 +87,7 @@ SYMBOLS = {
     "cf_split_bf16": (_i, [_f, _f, C.c_long, _i, _i, _i, _f]),
     "cf_head_tail": (_i, [C.POINTER(HeadTailArgs), _f]),
     "cf_head_fused": (_i, [C.POINTER(HeadFusedArgs), _f]),
+    "cf_pack_feat_mx": (_i, [_f, _i, _f, C.c_long, _f]),
     "cf_dcn_v2_fused": (_i, [C.POINTER(DcnArgs), _f]),
     "cf_dcn_v2_f16x3": (_i, [C.POINTER(DcnArgs), _f]),
     "cf_dcn_v2_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),

@@ -23,6 +23,10 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 hf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf16x32 __attribute__((ext_vector_type(32)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
 
 constexpr int HT_PX = 64;            // pixels per workgroup
 constexpr int HT_C = 256;            // hidden width
@@ -88,8 +92,9 @@ __device__ __forceinline__ void store_hidden_tile(unsigned char* xt, const f32x1
 
 // the same from 16x16 accumulators (v_mfma_f32_16x16x32_bf16: lane = pixel ct*16 + (l & 15), reg r = channel
 // 64w + 16rt + 4(l >> 4) + r) of one 64-pixel half tile
+template <bool SCALED = false>
 __device__ __forceinline__ void store_hidden_tile16(unsigned char* xt, const f32x4 (&acc)[4][4], const float* bias,
-                                                    int wave, int lane) {
+                                                    int wave, int lane, float sc = 1.0f) {
   const int g = lane >> 4, c16 = lane & 15;
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
@@ -100,7 +105,7 @@ __device__ __forceinline__ void store_hidden_tile16(unsigned char* xt, const f32
       float v[4], hi[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = fmaxf(acc[rt][ct][e] + bb[e], 0.0f);
+        v[e] = fmaxf(SCALED ? __builtin_fmaf(acc[rt][ct][e], sc, bb[e]) : acc[rt][ct][e] + bb[e], 0.0f);
         hi[e] = bf16_rne(v[e]);
       }
       unsigned char* o = xt + (ct * 16 + c16) * HT_ROWB + ch * 2;
@@ -620,6 +625,7 @@ struct HeadPatchK {
   const unsigned char* w_first[CF_MAX_HEADS];
   const float* b_first[CF_MAX_HEADS];
   const unsigned char* w_out_perm[CF_MAX_HEADS];
+  float first_scale[CF_MAX_HEADS];           // MX kernel: 2^-(s+4) of head i's first layer
 };
 
 template <int NS, bool PC>
@@ -857,9 +863,22 @@ __global__ __launch_bounds__(256, 2) void head_patch_kernel(HeadPatchK q) {
 // tiles give a lane 4 + 4 channels of one pixel = one B fragment, with w_out packed in that k order
 // (pack_fragments16(acc_order=True)); n_out <= 16.
 // ---------------------------------------------------------------------------------------------
-template <int NS, bool PC, bool TP>
+//
+// MX = true: the FIRST layer on "fp16 main term + block-scaled FP6 cross terms" (1.5 MFMA passes per product instead of the 3
+// of bf16x3; numerics and the gate that confines the scheme to the first layer: packing.pack_head_first_mx).  The
+// feature source is the 272-byte-per-pixel image cf_pack_feat_mx writes - [64 fp16 of 16 x][4 blocks of 32 FP6 e2m3 fields:
+// q6(xl) channels 0-31, 32-63, q6(xh) channels 0-31, 32-63; 32 B each, 24 used][one E8M0 scale byte per block][pad] - which IS
+// the LDS patch row.  Per tap: 2 k-steps of v_mfma_f32_16x16x32_f16 (weights' fp16 hi) and ONE v_mfma_scale_f32_16x16x128_f8f6f4
+// whose four 32-deep K blocks are q6(Wh) . q6(xl) (two 32-channel halves) and q6(Wl) . q6(xh): lane g = l >> 4 of either operand
+// holds K block g, with the block's scale byte in its lane.  Weights stream from L2 in (wave, tap) slabs, two items (of
+// main / main / cross) ahead.  pc_hm stays on bf16x3 with its weights pre-multiplied by 2^(s+4); the accumulators are scaled by
+// first_scale = 2^-(s+4) where the bias is added.  Hidden and output layers: unchanged bf16x3.
+// HID: -1 = n_hidden decided at run time (the bf16x3 instantiations); 0 / 1 = compiled for heads without / with hidden layers
+// (the MX instantiations: the register allocator then sees one of the two epilogues, not both).
+template <int NS, bool PC, bool TP, bool MX = false, int HID = -1>
 __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   static_assert(NS == 4, "64 feature channels");
+  constexpr int MX_SLAB = 14592, PC_OFF = MX ? 272 : NS * 64;      // (wave, tap) weight slab bytes; pc_hm planes inside a patch row
   // TP: the 128-pixel tile stands upright (16 rows x 8 columns) instead of 8 x 16 - same patch size (18 x 10 rows), chosen by
   // the host when it covers the map with fewer tiles (112 x 200: 7 x 25 = 175 exact tiles instead of 14 x 13 = 182)
   constexpr int TSH = TP ? 3 : 4, TMASK = (1 << TSH) - 1;          // pixel index -> (row = px >> TSH, column = px & TMASK)
@@ -887,7 +906,26 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   const int y0 = (rem / q.tiles_x) * T_H, x0 = (rem % q.tiles_x) * T_W;
 
   // ---- patch -> LDS (one pass, every load in flight before the first LDS write)
-  {
+  if constexpr (MX) {
+    constexpr int UPR = 17;                                // 16-byte units of a 272-byte mx row: the LDS row image itself
+    constexpr int NIT = (HP_ROWS * UPR + 255) / 256;
+    u32x4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx / UPR, u = idx % UPR;
+      const int y = y0 - 1 + row / P_W, x = x0 - 1 + row % P_W;
+      v[it] = u32x4{0u, 0u, 0u, 0u};                       // outside the image: zero fields with scale byte 0 (2^-127): exact zeros
+      if (row < HP_ROWS && (unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W)
+        v[it] = *reinterpret_cast<const u32x4*>(q.src[0] + (size_t)(b * p.HW + y * q.W + x) * 272 + u * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx / UPR, u = idx % UPR;
+      if (row < HP_ROWS) *reinterpret_cast<u32x4*>(xt + row * ROWB + u * 16) = v[it];
+    }
+  } else {
     constexpr int UPR = NS * 4;                            // 16-byte units per row: hi plane then lo plane
     constexpr int NIT = (HP_ROWS * UPR + 255) / 256;
     u32x4 v[NIT];
@@ -908,15 +946,15 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
       const int plane = u / (NS * 2), uu = u % (NS * 2);
       if (row < HP_ROWS) *reinterpret_cast<u32x4*>(xt + row * ROWB + (uu >> 1) * 64 + plane * 32 + (uu & 1) * 16) = v[it];
     }
-    if (PC) {
-      for (int idx = tid; idx < HP_ROWS * 2; idx += 256) {
-        const int row = idx >> 1, plane = idx & 1;
-        const int y = y0 - 1 + row / P_W, x = x0 - 1 + row % P_W;
-        u32x4 w = {0u, 0u, 0u, 0u};
-        if ((unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W)
-          w = *reinterpret_cast<const u32x4*>(q.src[1] + ((size_t)(b * p.HW + y * q.W + x) * 2 + plane) * q.src_c[1] * 2);
-        *reinterpret_cast<u32x4*>(xt + row * ROWB + NS * 64 + plane * 16) = w;
-      }
+  }
+  if (PC) {
+    for (int idx = tid; idx < HP_ROWS * 2; idx += 256) {
+      const int row = idx >> 1, plane = idx & 1;
+      const int y = y0 - 1 + row / P_W, x = x0 - 1 + row % P_W;
+      u32x4 w = {0u, 0u, 0u, 0u};
+      if ((unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W)
+        w = *reinterpret_cast<const u32x4*>(q.src[1] + ((size_t)(b * p.HW + y * q.W + x) * 2 + plane) * q.src_c[1] * 2);
+      *reinterpret_cast<u32x4*>(xt + row * ROWB + PC_OFF + plane * 16) = w;
     }
   }
 
@@ -931,10 +969,133 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int t = min(4 * i + g, 8);
-    pc_off[i] = ((t / 3) * P_W + t % 3) * ROWB + NS * 64;
+    pc_off[i] = ((t / 3) * P_W + t % 3) * ROWB + PC_OFF;
   }
   __syncthreads();                           // the patch is complete
   auto first_layer = [&](int head, f32x4 (&acc)[4][8]) __attribute__((always_inline)) {
+  if constexpr (MX) {
+    const unsigned char* wb = q.w_first[head] + (size_t)wave * (9 * MX_SLAB);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][c][r] = 0.0f;
+    hf16x8 am[2][4];                         // fp16 hi fragments of the tap's two k-steps
+    u32x4 ax0[4];                            // FP6 fragments of the tap's cross term: 24 B per lane and row tile
+    u32x2 ax1[4];
+    int sa;                                  // their E8M0 scale bytes, byte rt
+    // buffer loads: a scalar resource per (wave, tap) slab + a per-lane 32-bit offset + small constants - no 64-bit address
+    // arithmetic and no address register pairs in a loop that has every register in use
+    auto slab = [&](int tap) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wb + tap * MX_SLAB), 0, MX_SLAB, 0x00020000);
+    };
+    const int l16 = lane * 16, l8 = lane * 8, l4 = lane * 4;
+    auto ldm = [&](hf16x8 (&d)[4], int tap, int ks2) {
+      const __amdgpu_buffer_rsrc_t rs = slab(tap);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        d[rt] = __builtin_bit_cast(hf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, (rt * 2 + ks2) * 1024, 0));
+    };
+    auto ldx = [&](int tap) {
+      const __amdgpu_buffer_rsrc_t rs = slab(tap);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        ax0[rt] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, l16, 8192 + rt * 1536, 0));
+        ax1[rt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, l8, 8192 + rt * 1536 + 1024, 0));
+      }
+      sa = (int)__builtin_amdgcn_raw_buffer_load_b32(rs, l4, 14336, 0);
+    };
+    // one half (tile rows 4 hf .. 4 hf + 3) of a main k-step / one quarter pair (tile rows 2 pr, 2 pr + 1) of a cross step
+    auto main_half = [&](const hf16x8 (&A)[4], int off, int hf) {
+      hf16x8 xb[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) xb[ct] = *reinterpret_cast<const hf16x8*>(xt + rowb[4 * hf + ct] + off);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[rt][4 * hf + ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[rt], xb[ct], acc[rt][4 * hf + ct], 0, 0, 0);
+    };
+    auto cross_pair = [&](int toff, int pr) {
+      i32x8 xb[2];
+      int sb[2];
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const unsigned char* r = xt + rowb[2 * pr + c2] + toff;
+        const u32x4 b0 = *reinterpret_cast<const u32x4*>(r + 128 + 32 * g);
+        const u32x2 b1 = *reinterpret_cast<const u32x2*>(r + 128 + 32 * g + 16);
+        xb[c2] = i32x8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], 0, 0};
+        sb[c2] = (int)(*reinterpret_cast<const unsigned*>(r + 256) >> (8 * g));     // this lane's block: byte g -> byte 0
+      }
+#define CF_MX_ROW(RT)                                                                                                   \
+      {                                                                                                                 \
+        const i32x8 a6 = {(int)ax0[RT][0], (int)ax0[RT][1], (int)ax0[RT][2], (int)ax0[RT][3], (int)ax1[RT][0],          \
+                          (int)ax1[RT][1], 0, 0};                                                                       \
+        _Pragma("unroll") for (int c2 = 0; c2 < 2; ++c2)                                                                \
+          acc[RT][2 * pr + c2] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a6, xb[c2], acc[RT][2 * pr + c2],    \
+                                                                                  2, 2, RT, sa, 0, sb[c2]);             \
+      }
+      CF_MX_ROW(0) CF_MX_ROW(1) CF_MX_ROW(2) CF_MX_ROW(3)
+#undef CF_MX_ROW
+    };
+    ldm(am[0], 0, 0);
+    ldm(am[1], 0, 1);
+    ldx(0);
+    // Items per tap: main k-step 0, main k-step 1, cross.  The operands of the item two behind are requested in the MIDDLE
+    // of an item (its buffer was freed by the item before), with the only sched_barrier of the item right behind the
+    // requests: they cannot sink to their first use, while the LDS reads of the NEXT item's first half may rise above the
+    // second half's MFMAs (an item is 32 MFMAs: a barrier at its end would expose an LDS round trip per item).
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int toff = ((tap / 3) * P_W + tap % 3) * ROWB;
+      main_half(am[0], toff + g * 16, 0);                  // channels 0-31: lane group g holds 8 g .. 8 g + 7
+      if (tap > 0) ldx(tap);                               // (cross operands of THIS tap: freed by the item before)
+      __builtin_amdgcn_sched_barrier(0);
+      main_half(am[0], toff + g * 16, 1);
+      main_half(am[1], toff + 64 + g * 16, 0);             // channels 32-63
+      if (tap + 1 < 9) ldm(am[0], tap + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      main_half(am[1], toff + 64 + g * 16, 1);
+      cross_pair(toff, 0);
+      cross_pair(toff, 1);
+      if (tap + 1 < 9) ldm(am[1], tap + 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      cross_pair(toff, 2);
+      cross_pair(toff, 3);
+    }
+    __builtin_amdgcn_sched_barrier(0);       // (the epilogue's loads stay behind the last item)
+    if (PC) {                                // pc_hm on bf16x3: 3 k-steps of 4 taps x 8 channels, weights x 2^(s+4)
+      const unsigned char* wp = q.w_first[head] + (size_t)4 * 9 * MX_SLAB + (size_t)wave * (3 * 4 * 2048);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        bf16x8 ph[4], pl[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          ph[rt] = *reinterpret_cast<const bf16x8*>(wp + (i * 4 + rt) * 2048 + (unsigned)lane * 16u);
+          pl[rt] = *reinterpret_cast<const bf16x8*>(wp + (i * 4 + rt) * 2048 + 1024 + (unsigned)lane * 16u);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          bf16x8 xh[4], xl[4];
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) {
+            xh[ct] = *reinterpret_cast<const bf16x8*>(xt + rowb[4 * hf + ct] + pc_off[i]);
+            xl[ct] = *reinterpret_cast<const bf16x8*>(xt + rowb[4 * hf + ct] + pc_off[i] + 16);
+          }
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+              acc[rt][4 * hf + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[rt], xh[ct], acc[rt][4 * hf + ct], 0, 0, 0);
+              acc[rt][4 * hf + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rt], xl[ct], acc[rt][4 * hf + ct], 0, 0, 0);
+              acc[rt][4 * hf + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rt], xh[ct], acc[rt][4 * hf + ct], 0, 0, 0);
+            }
+        }
+      }
+    }
+    return;
+  }
   const unsigned char* w1 = q.w_first[head];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -993,7 +1154,7 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   }
   };
 
-  if (p.n_hidden > 0) {                      // (the host launches these with hloop == 1)
+  if (HID < 0 ? p.n_hidden > 0 : HID == 1) {   // (the host launches these with hloop == 1)
     const int head = head0;
     f32x4 acc[4][8];
     first_layer(head, acc);
@@ -1007,13 +1168,15 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) a2[rt][ct] = acc[rt][4 * half + ct];
-      store_hidden_tile16(xt, a2, q.b_first[head], wave, lane);
+      store_hidden_tile16<MX>(xt, a2, q.b_first[head], wave, lane, MX ? q.first_scale[head] : 1.0f);
+      if constexpr (MX) __builtin_amdgcn_sched_barrier(0);     // (the chain's first weight loads stay behind the tile stores)
       __syncthreads();
       head_tail_from_lds16(p, xt, head, TileMap{b, y0 + (64 >> TSH) * half, x0, q.H, q.W, TSH});
       __syncthreads();
     }
     return;
   }
+  if constexpr (HID == 1) return;
 
   for (int head = head0; head < head1; ++head) {
   f32x4 acc[4][8];
@@ -1027,6 +1190,8 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   {
     const float* b1 = q.b_first[head] + wave * 64 + 4 * g;
     const unsigned char* wo = q.w_out_perm[head];
+    const float fsc = MX ? q.first_scale[head] : 1.0f;
+    (void)fsc;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const int ks2 = wave * 2 + s2;
@@ -1038,7 +1203,8 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
         float v[8], hi[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          v[j] = fmaxf(acc[2 * s2 + (j >> 2)][ct][j & 3] + (j < 4 ? ba[j] : bb[j - 4]), 0.0f);
+          const float bj = j < 4 ? ba[j] : bb[j - 4];
+          v[j] = fmaxf(MX ? __builtin_fmaf(acc[2 * s2 + (j >> 2)][ct][j & 3], fsc, bj) : acc[2 * s2 + (j >> 2)][ct][j & 3] + bj, 0.0f);
           hi[j] = bf16_rne(v[j]);
         }
         const u32x4 ph = {pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7])};
@@ -1084,7 +1250,81 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   }                                          // head loop
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp32 NHWC feature map -> the 272-byte mx rows head_patch16_kernel<.., MX> stages (layout: there).  One thread per
+// (pixel, 32-channel block): v = clamp(16 x), hi = fp16(v), lo = v - hi (exact); block exponent = smallest e with
+// max|.| <= 7.5 * 2^e, from the bits of the maximum (exponent field - 2, + 1 if the mantissa exceeds 1.875); fields by
+// v_cvt_scalef32_pk32_fp6_f16 / v_cvt_scalef32_2xpk16_fp6_f32 (RNE, field j = channel j).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mx_block_exp(float amax) {   // amax >= 0
+  const int bits = __builtin_bit_cast(int, amax);
+  const int e = ((bits >> 23) & 0xff) - 127 - 2 + ((bits & 0x7fffff) > 0x700000 ? 1 : 0);
+  return amax == 0.0f ? -127 : e;
+}
+
+__global__ __launch_bounds__(256) void pack_feat_mx_kernel(const float* __restrict__ x, int in_stride,
+                                                           unsigned char* __restrict__ rows, long M) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long m = t >> 1;
+  const int blk = (int)(t & 1);
+  if (m >= M) return;
+  const f32x4* src = reinterpret_cast<const f32x4*>(x + m * in_stride + 32 * blk);
+  f32x4 q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] = src[i];
+  hf16x32 h;
+  f32x16 le, lo_;                              // lo: even / odd channels (the f32 convert interleaves its two sources)
+  float mh = 0.0f, ml = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const float v = __builtin_amdgcn_fmed3f(q[j >> 2][j & 3] * 16.0f, -65504.0f, 65504.0f);
+    const _Float16 hj = (_Float16)v;
+    const float l = v - (float)hj;
+    h[j] = hj;
+    if (j & 1) lo_[j >> 1] = l; else le[j >> 1] = l;
+    mh = fmaxf(mh, fabsf((float)hj));
+    ml = fmaxf(ml, fabsf(l));
+  }
+  const int eh = mx_block_exp(mh), el = mx_block_exp(ml);
+  // (a block of zeros converts with scale 1: 0 / 2^-127 would do as well, this keeps the divide away from the edge)
+  const float sh = mh == 0.0f ? 1.0f : __builtin_bit_cast(float, (eh + 127) << 23);
+  const float sl = ml == 0.0f ? 1.0f : __builtin_bit_cast(float, (el + 127) << 23);
+  // inline asm with an early-clobber destination: hipcc (ROCm 7.2) may allocate the 6-dword result ON TOP of the scale
+  // (or a source) register of the builtin form, and the instruction writes its result in passes while still reading them
+  // - every field behind the first pair then converts with a clobbered scale (seen: v_cvt_... v[0:5], .., .., v0)
+  i32x6 h6, l6;
+  asm volatile("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(h6) : "v"(h), "v"(sh));
+  asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(l6) : "v"(le), "v"(lo_), "v"(sl));
+  unsigned char* row = rows + m * 272;
+  {
+    u32x4* o = reinterpret_cast<u32x4*>(row + 64 * blk);
+    const u32x4* hs = reinterpret_cast<const u32x4*>(&h);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = hs[i];
+  }
+  *reinterpret_cast<u32x4*>(row + 128 + 32 * blk) = u32x4{(unsigned)l6[0], (unsigned)l6[1], (unsigned)l6[2], (unsigned)l6[3]};
+  *reinterpret_cast<u32x4*>(row + 144 + 32 * blk) = u32x4{(unsigned)l6[4], (unsigned)l6[5], 0u, 0u};
+  *reinterpret_cast<u32x4*>(row + 192 + 32 * blk) = u32x4{(unsigned)h6[0], (unsigned)h6[1], (unsigned)h6[2], (unsigned)h6[3]};
+  *reinterpret_cast<u32x4*>(row + 208 + 32 * blk) = u32x4{(unsigned)h6[4], (unsigned)h6[5], 0u, 0u};
+  row[256 + blk] = (unsigned char)(el + 127);
+  row[258 + blk] = (unsigned char)(eh + 127);
+  if (blk == 0) {
+    *reinterpret_cast<unsigned*>(row + 260) = 0u;
+    *reinterpret_cast<u32x2*>(row + 264) = u32x2{0u, 0u};
+  }
+}
+
 }  // namespace
+
+extern "C" int cf_pack_feat_mx(const float* x, int in_stride, void* rows, long M, void* stream) {
+  CF_REQUIRE(x && rows && M > 0, "cf_pack_feat_mx: null tensor or M=%ld", M);
+  CF_REQUIRE(in_stride >= 64 && in_stride % 4 == 0, "cf_pack_feat_mx: in_stride=%d (64 channels, 16-byte aligned rows)", in_stride);
+  CF_REQUIRE(M < (1L << 30), "cf_pack_feat_mx: M=%ld too large", M);
+  const long threads = 2 * M;
+  hipLaunchKernelGGL(pack_feat_mx_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     in_stride, static_cast<unsigned char*>(rows), M);
+  return cf_check_launch("cf_pack_feat_mx");
+}
 
 static int fill_tail(const cf_head_tail_args* a, HeadTailK& k, const char* who, bool need_x) {
   CF_REQUIRE(a != nullptr, "%s: null args", who);
@@ -1144,8 +1384,13 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
     k.src[i] = reinterpret_cast<const unsigned char*>(a->src[i]);
     k.src_c[i] = a->src_c[i];
   }
-  CF_REQUIRE(a->slots && a->K_pad > 0 && a->K_pad % 64 == 0, "cf_head_fused: K_pad=%d must be a multiple of 64", a->K_pad);
-  CF_REQUIRE(a->K_pad / 32 <= HF_MAX_CHUNKS, "cf_head_fused: K_pad=%d exceeds %d", a->K_pad, HF_MAX_CHUNKS * 32);
+  if (a->mx) {                             // the mx operand stream has no slot table: only the 3x3 patch kernel reads it
+    CF_REQUIRE(a->layout3x3 && a->mfma16 && a->src_c[0] == 64 && (a->n_src == 1 || a->src_c[1] == 8),
+               "cf_head_fused: mx = 1 needs layout3x3 = 1, mfma16 = 1, a 64-channel mx source [and an 8-channel pc_hm source]");
+  } else {
+    CF_REQUIRE(a->slots && a->K_pad > 0 && a->K_pad % 64 == 0, "cf_head_fused: K_pad=%d must be a multiple of 64", a->K_pad);
+    CF_REQUIRE(a->K_pad / 32 <= HF_MAX_CHUNKS, "cf_head_fused: K_pad=%d exceeds %d", a->K_pad, HF_MAX_CHUNKS * 32);
+  }
   k.slots = a->slots;
   k.n_chunks = a->K_pad / 32;
   k.H = a->tail.H;
@@ -1165,10 +1410,16 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
     hp.tiles_x = (k.W + HP_TW - 1) / HP_TW;
     hp.tiles_y = (k.H + HP_TH - 1) / HP_TH;
     const bool m16 = a->mfma16 != 0;         // fragments packed for v_mfma_f32_16x16x32_bf16 (k-steps of 32)
+    const bool mx = a->mx != 0;              // first layer: fp16 main + FP6 cross terms on the mx feature rows
+    CF_REQUIRE(!mx || m16, "cf_head_fused: mx = 1 needs mfma16 = 1 (the tail layers run on 16x16x32 fragments)");
     hp.n_ks = m16 ? a->K_pad / 32 : a->K_pad / 16;
-    CF_REQUIRE(a->K_pad / 16 >= (a->n_src == 2 ? 41 : 36), "cf_head_fused: K_pad=%d too small for the 3x3 layout", a->K_pad);
+    CF_REQUIRE(mx || a->K_pad / 16 >= (a->n_src == 2 ? 41 : 36), "cf_head_fused: K_pad=%d too small for the 3x3 layout", a->K_pad);
+    for (int i = 0; i < a->tail.n_heads; ++i) {
+      CF_REQUIRE(!mx || (a->first_scale[i] > 0.0f && a->first_scale[i] < 1e30f), "cf_head_fused: head %d: first_scale missing (mx)", i);
+      hp.first_scale[i] = a->first_scale[i];
+    }
     if (m16) {
-      CF_REQUIRE(a->K_pad % 32 == 0 && a->K_pad / 32 >= (a->n_src == 2 ? 21 : 18), "cf_head_fused: K_pad=%d (16x16x32 fragments)", a->K_pad);
+      CF_REQUIRE(mx || (a->K_pad % 32 == 0 && a->K_pad / 32 >= (a->n_src == 2 ? 21 : 18)), "cf_head_fused: K_pad=%d (16x16x32 fragments)", a->K_pad);
       for (int i = 0; i < a->tail.n_heads; ++i)
         CF_REQUIRE(a->tail.n_out[i] <= 16, "cf_head_fused: head %d: n_out=%d > 16 (the 16x16x32 kernels produce ONE 16-row output tile, with or without hidden layers)", i, a->tail.n_out[i]);
     }
@@ -1235,7 +1486,23 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
         lim.ensure(kernel, lds, hp16_lds(pc, false));
         hipLaunchKernelGGL(kernel, dim3((unsigned)blocks16), dim3(256), lds, (hipStream_t)stream, hp);
       };
-      static CfLdsLimit lim16[4];
+      static CfLdsLimit lim16[4], limx[4];
+      if (mx) {
+        static CfLdsLimit limxh[2];
+        if (hidden) {
+          // (hidden layers behind an mx first layer WITHOUT the pc_hm source: that instantiation does not fit 256 registers
+          //  without scratch, and no configuration of the reference has such heads - its packing stays bf16x3)
+          CF_REQUIRE(pc, "cf_head_fused: mx = 1 with hidden layers needs the pc_hm source (n_src = 2); pack such heads for bf16x3");
+          if (portrait) launch(head_patch16_kernel<4, true, true, true, 1>, limxh[1]);
+          else launch(head_patch16_kernel<4, true, false, true, 1>, limxh[0]);
+        } else {
+          if (pc && portrait) launch(head_patch16_kernel<4, true, true, true, 0>, limx[3]);
+          else if (pc) launch(head_patch16_kernel<4, true, false, true, 0>, limx[2]);
+          else if (portrait) launch(head_patch16_kernel<4, false, true, true, 0>, limx[1]);
+          else launch(head_patch16_kernel<4, false, false, true, 0>, limx[0]);
+        }
+        return cf_check_launch("cf_head_fused");
+      }
       if (pc && portrait) launch(head_patch16_kernel<4, true, true>, lim16[3]);
       else if (pc) launch(head_patch16_kernel<4, true, false>, lim16[2]);
       else if (portrait) launch(head_patch16_kernel<4, false, true>, lim16[1]);

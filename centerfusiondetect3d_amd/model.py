@@ -447,7 +447,14 @@ class _Plan:
             y = out[:3]
             ida("ida_up", y, 0, 3, final_out=feat)
             feat = y[-1]
-            if bf:
+            if bf and model._mx_active:
+                # heads' first layer on fp16 + FP6 (cf_head_fused mx = 1): the 272-byte rows it stages, one pass over the
+                # fp32 feature map of this (sub-)batch
+                if feat_in is None:
+                    feat_in = buf(B, h4, w4, packing.MX_ROW, dtype=torch.uint8)
+                self.step_index["feat.pack_mx"] = len(self.steps)
+                self.add_step((self.lib.cf_pack_feat_mx, feat.data_ptr(), 64, feat_in.data_ptr(), C.c_long(B * h4 * w4)))
+            elif bf:
                 # the split-bf16 copy of the feature map the heads read is written by the epilogue of the DCN
                 # that produces it (f16x3 kernel); a separate split pass only if that kernel is not in use
                 if feat_in is None:
@@ -523,7 +530,7 @@ class _Plan:
         def fused_heads(name, names, srcs, strides):
             """One cf_head_fused launch: 3x3 + ReLU + tail for sibling heads, hidden never in HBM."""
             hd = [dict(pk[name][h], act=act_of(h)) for h in names]
-            f = ops.head_fused_args(srcs, strides, hd[0]["slots"], hd[0]["k_pad"], B, h4, w4, hd)
+            f = ops.head_fused_args(srcs, strides, hd[0].get("slots"), hd[0].get("k_pad", 0), B, h4, w4, hd)
             self.keep.append(f)
             for n, h in enumerate(names):
                 self.tails[h] = (f.tail, n)
@@ -746,6 +753,10 @@ class DLASeg(nn.Module):
         self.heads_fused = True  # with heads_bf16: one launch per head group, hidden maps stay in LDS
         self.heads_mfma16 = True # fused heads: first layer + register-fed output layer on v_mfma_f32_16x16x32_bf16 (the
                                  # shape that holds the higher clock under load: 1.72 vs 1.51 PFLOP/s measured)
+        self.heads_mx = True     # ... and the FIRST layer of every fused head as fp16 main term + block-scaled FP6 cross terms
+                                 # (v_mfma_scale_f32_16x16x128_f8f6f4): 1.5 MFMA passes per product instead of 3; hidden and
+                                 # output layers stay bf16x3 (the float64-anchored gate rejects FP6 cross terms there)
+        self._mx_active = False  # set by _pack: heads_mx and everything it needs (bf16 fused heads on 16x16x32 fragments)
         self.record_spans = False  # dev / tests: keep HIP events around each trunk of _forward_concurrent (trunk_overlap)
         self.trunk_spans = []
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
@@ -799,6 +810,7 @@ class DLASeg(nn.Module):
     def _prepare(self, device):
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         pk = {}
+        self._mx_active = False
 
         def bn(p):
             return (sd[p + ".weight"], sd[p + ".bias"], sd[p + ".running_mean"], sd[p + ".running_var"])
@@ -910,7 +922,13 @@ class DLASeg(nn.Module):
                             b_hidden=[hb(h, i).to(device) for i in hidden_idx],
                             w_out=pf(w2).to(device), w_out_perm=perm.to(device),
                             b_out=b32.to(device), n_out=n_out, mfma16=m16)
+            mx = m16 and bool(self.heads_mx)
+            self._mx_active = mx
             def first(h, srcs):
+                if mx:
+                    d = packing.pack_head_first_mx(hw(h, 0), hb(h, 0), pc=len(srcs) == 2)
+                    return dict(w_first=d["w_first"].to(device), b_first=d["b_first"].to(device), first_scale=d["first_scale"],
+                                real_cin=d["real_cin"])
                 pc = packing.pack_conv_bf16(hw(h, 0), hb(h, 0), srcs, fragments=16 if m16 else True).to(device)
                 return dict(w_first=pc.weight, b_first=pc.bias[:256].contiguous(), slots=pc.slots, k_pad=pc.k_pad,
                             real_cin=pc.real_cin)
@@ -1036,7 +1054,10 @@ class DLASeg(nn.Module):
 
         def heads_plan():
             feat = torch.empty((B, h4, w4, 64), device=dev, dtype=torch.float32)
-            feat_in = torch.empty((B, h4, w4, 2, 64), device=dev, dtype=torch.bfloat16) if bf else feat
+            if bf and self._mx_active:
+                feat_in = torch.empty((B, h4, w4, packing.MX_ROW), device=dev, dtype=torch.uint8)
+            else:
+                feat_in = torch.empty((B, h4, w4, 2, 64), device=dev, dtype=torch.bfloat16) if bf else feat
             return _Plan(self, B, H, W, dev, part="heads", feat=feat, feat_in=feat_in)
 
         hplan = self._plan((B, H, W, dev, sid, "heads", n), heads_plan, store)

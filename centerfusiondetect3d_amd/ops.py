@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, ACT_RAW_AND_SIGDEPTH, LAYOUT_NHWC,
                    LAYOUT_NCHW, LAYOUT_NHWC_SPLIT_BF16)
-from .packing import PackedConv, PackedDcn
+from .packing import PackedConv, PackedDcn, MX_ROW as packing_MX_ROW
 
 
 def _need_cuda(*ts):
@@ -170,7 +170,7 @@ def head_fused_args(srcs, src_strides, slots, k_pad, B, H, W, heads, layout3x3=N
     for i, (s, c) in enumerate(zip(srcs, src_strides)):
         f.src[i], f.src_c[i] = s.data_ptr(), c
     f.n_src = len(srcs)
-    f.slots, f.K_pad = slots.data_ptr(), k_pad
+    f.slots, f.K_pad = (slots.data_ptr() if slots is not None else None), int(k_pad or 0)   # (mx: no slot table)
     for i, hd in enumerate(heads):
         f.w_first[i], f.b_first[i] = hd["w_first"].data_ptr(), hd["b_first"].data_ptr()
         if hd.get("w_out_perm") is not None:
@@ -178,7 +178,24 @@ def head_fused_args(srcs, src_strides, slots, k_pad, B, H, W, heads, layout3x3=N
     f.layout3x3 = int(all(hd.get("w_out_perm") is not None for hd in heads)) if layout3x3 is None else int(layout3x3)
     f.mfma16 = int(all(bool(hd.get("mfma16")) for hd in heads))     # fragments packed for the 16x16x32 shape (the C
     # side refuses them on a launch that does not take the 3x3 patch kernel: nothing else can read them)
+    f.mx = int(all(hd.get("first_scale") is not None for hd in heads))   # packing.pack_head_first_mx streams: srcs[0] = mx rows
+    if f.mx:
+        for i, hd in enumerate(heads):
+            f.first_scale[i] = float(hd["first_scale"])
     return f
+
+
+def pack_feat_mx(feat, out=None):
+    """feat (..., C >= 64) fp32 NHWC (the first 64 channels are the feature map) -> (..., 272) uint8 rows for
+    cf_head_fused with mx = 1 (include/cf_hip.h: cf_pack_feat_mx)."""
+    _need_cuda(feat)
+    assert feat.dtype == torch.float32 and feat.is_contiguous() and feat.shape[-1] >= 64
+    M = feat.numel() // feat.shape[-1]
+    if out is None:
+        out = torch.empty(feat.shape[:-1] + (packing_MX_ROW,), device=feat.device, dtype=torch.uint8)
+    _lib.check(_lib.load().cf_pack_feat_mx(feat.data_ptr(), feat.shape[-1], out.data_ptr(), M, _lib.stream_ptr()),
+               "cf_pack_feat_mx")
+    return out
 
 
 def run_head_fused(f):

@@ -378,3 +378,103 @@ def pack_stem(w_base, b_base, w_l0, b_l0, w_l1, b_l1) -> PackedStem:
     f1, s2 = frag3(w_l1)
     return PackedStem(fb, b_base.float().clone(), f0[0].contiguous(), b_l0.float().clone(), f1, b_l1.float().clone(),
                       2.0 ** -(s0 + 4), 2.0 ** -(s1 + 4), 2.0 ** -(s2 + 4))
+
+
+# ------------------------------------------------------------------------------------------------
+# Heads, first layer: "f16 main term + block-scaled FP6 cross terms" (cf_head_fused with mx = 1).
+#
+#   W * 2^s = Wh + Wl  (Wh fp16 RNE, Wl the exact remainder),   x * 16 = xh + xl  (the same, per element)
+#   acc = Wh . xh                                  v_mfma_f32_16x16x32_f16, exact products
+#       + q6(Wh) . q6(xl) + q6(Wl) . q6(xh)        ONE v_mfma_scale_f32_16x16x128_f8f6f4 per tap: K = [32 ch | 32 ch | 32 ch | 32 ch]
+#   y   = acc * 2^-(s + 4) + b
+#
+# q6 = OCP MX FP6 e2m3 with one E8M0 scale per block of 32 channels of one tap (weights: per output row).  The scheme
+# costs 1.5 MFMA passes per product instead of 3; its error (4 significant bits on terms that are 2^-11 of the product)
+# passes the float64-anchored gate of tests/test_gpu_model.py ONLY on the first layer (docs/experiments/r5_heads_mx_numerics.txt),
+# so the hidden and output layers stay bf16x3.
+# ------------------------------------------------------------------------------------------------
+MX_SLAB = 14592          # bytes of one (wave, tap) slab: 4 row tiles x 2 k-steps x 1 KiB | 4 x (1 KiB + 512 B) | 256 B of scales
+MX_ROW = 272             # bytes of one pixel of the mx feature map: 64 fp16 | 4 x 32 B FP6 blocks | 4 scale bytes | pad
+
+
+def e2m3_encode(t):
+    """float64 tensor t (already divided by the block scale) -> uint8 e2m3 codes, RNE, saturating at 7.5; the sign bit
+    follows signbit(t) also when the magnitude rounds to zero (as v_cvt_scalef32_*_fp6_* does)."""
+    a = t.abs().clamp(max=7.5)
+    q_lo = torch.round(a * 8.0)                  # [0, 2): step 1/8, codes 0..16
+    q_mid = 16 + (torch.round(a * 4.0) - 8)      # [2, 4): step 1/4, codes 16..24
+    q_hi = 24 + (torch.round(a * 2.0) - 8)       # [4, 7.5]: step 1/2, codes 24..31
+    code = torch.where(a < 2.0, q_lo, torch.where(a < 4.0, q_mid, q_hi)).clamp(max=31).to(torch.int64)
+    return (code | (torch.signbit(t).to(torch.int64) << 5)).to(torch.uint8)
+
+
+def mx_block_exponent(amax):
+    """smallest integer e with amax <= 7.5 * 2^e, from the fp32 bits of amax (the rule the kernels use): exponent field
+    k, e = k - 2 + (mantissa > 0x700000).  amax == 0 -> -127 (scale byte 0)."""
+    bits = amax.float().contiguous().view(torch.int32)
+    k = ((bits >> 23) & 0xFF) - 127
+    e = k - 2 + ((bits & 0x7FFFFF) > 0x700000).to(torch.int32)
+    return torch.where(amax.float() == 0, torch.full_like(e, -127), e).clamp(-127, 127)
+
+
+def pack_fp6_fields(codes):
+    """(..., 32) uint8 codes -> (..., 24) uint8: element j in bits [6j, 6j + 6), little endian."""
+    c = codes.to(torch.int64).reshape(*codes.shape[:-1], 8, 4)           # 4 codes -> 3 bytes
+    w = c[..., 0] | (c[..., 1] << 6) | (c[..., 2] << 12) | (c[..., 3] << 18)
+    out = torch.stack([w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFF], -1)
+    return out.reshape(*codes.shape[:-1], 24).to(torch.uint8)
+
+
+def mx_quant_blocks(v):
+    """v (..., 32 n) float -> (codes uint8 (..., n, 32), scale bytes uint8 (..., n)) with one E8M0 scale per 32 entries."""
+    b = v.double().reshape(*v.shape[:-1], v.shape[-1] // 32, 32)
+    e = mx_block_exponent(b.abs().amax(-1).float())
+    codes = e2m3_encode(b / torch.pow(2.0, e.double()).unsqueeze(-1))
+    return codes, (e + 127).to(torch.uint8)
+
+
+def pack_head_first_mx(weight, bias, pc: bool):
+    """First 3x3 layer of one head (256, 64 [+3], 3, 3) -> the operand stream of head_patch16_kernel<..., MX>.
+
+    Returns dict(w_first uint8, b_first f32 (256), first_scale 2^-(s+4), real_cin).  Layout of w_first: for wave wv
+    (64 output channels = 4 row tiles of 16) and tap t a slab of MX_SLAB bytes:
+        [rt 4][ks 2][lane 64][8 fp16]   main term: lane (g = l >> 4, i = l & 15) holds Wh[64 wv + 16 rt + i][t, 32 ks + 8 g + j]
+        [rt 4]([lane 64][16 B] | [lane 64][8 B])   cross term, 24 B per lane = 32 FP6 fields: g = 0, 1: q6(Wh) channels
+                                        32 g .. +32 (to meet q6(xl)); g = 2, 3: q6(Wl) channels 32 (g - 2) .. +32 (to meet q6(xh))
+        [lane 64][4 B]                  E8M0 scale bytes of that lane's block, byte rt
+    then (pc only) the pc_hm part as bf16x3 fragments of W * 2^(s+4): [wv 4][ks 3][rt 4][hi, lo][lane 64][8 bf16], k-step ks =
+    taps 4 ks .. 4 ks + 3 x 8 channels (3 real)."""
+    co, ci, kh, kw = weight.shape
+    assert co == 256 and (kh, kw) == (3, 3) and ci == (67 if pc else 64)
+    w = weight.double()
+    wmax = float(w.abs().max())
+    s_exp = int(torch.floor(torch.log2(torch.tensor(16384.0 / wmax)))) if wmax > 0 else 0
+    ws = (w[:, :64] * 2.0 ** s_exp).float().permute(0, 2, 3, 1).reshape(256, 9, 64)      # (row, tap, channel)
+    hi = ws.to(torch.float16)
+    lo = ws - hi.float()                                                               # exact
+    hc, hs = mx_quant_blocks(hi.float())                                                # (256, 9, 2, 32), (256, 9, 2)
+    lc, ls = mx_quant_blocks(lo)
+    hf, lf = pack_fp6_fields(hc), pack_fp6_fields(lc)                                   # (256, 9, 2, 24)
+    out = torch.zeros(4, 9, MX_SLAB, dtype=torch.uint8)
+    # main: [wv][tap][rt][ks][g][i][8] <- hi[(wv, rt, i)][tap][(ks, g, j)]
+    m = hi.view(4, 4, 16, 9, 2, 4, 8).permute(0, 3, 1, 4, 5, 2, 6).contiguous()        # wv, tap, rt, ks, g, i, j
+    out[:, :, :8192] = m.view(torch.uint8).reshape(4, 9, 8192)
+    # cross: lane (g, i): g = 0, 1 -> hf block g; g = 2, 3 -> lf block g - 2
+    x = torch.cat([hf, lf], 2).view(4, 4, 16, 9, 4, 24).permute(0, 3, 1, 4, 2, 5).contiguous()   # wv, tap, rt, g, i, 24
+    x = x.view(4, 9, 4, 64, 24)
+    out[:, :, 8192:8192 + 6144] = torch.cat([x[..., :16].reshape(4, 9, 4, 1024), x[..., 16:].reshape(4, 9, 4, 512)], -1).reshape(4, 9, 6144)
+    sc = torch.cat([hs, ls], 2).view(4, 4, 16, 9, 4).permute(0, 3, 4, 2, 1).contiguous()          # wv, tap, g, i, rt
+    out[:, :, 14336:] = sc.view(4, 9, 256)
+    parts = [out.reshape(-1)]
+    if pc:
+        wp = torch.zeros(256, 12, 8, dtype=torch.float64)                               # (row, tap (9 real), 8 ch (3 real))
+        wp[:, :9, :3] = (w[:, 64:67] * 2.0 ** (s_exp + 4)).permute(0, 2, 3, 1).reshape(256, 9, 3)
+        wp = wp.float().view(256, 3, 32)                                                # k-step ks: k = 8 (tap - 4 ks) + c
+        ph = wp.to(torch.bfloat16)
+        pl = (wp - ph.float()).to(torch.bfloat16)
+        f = torch.stack([ph, pl], 0).view(2, 4, 4, 16, 3, 4, 8).permute(1, 4, 2, 0, 5, 3, 6).contiguous()   # wv, ks, rt, plane, g, i, j
+        parts.append(f.view(torch.uint8).reshape(-1))
+    b = torch.zeros(256)
+    b[:co] = bias.float()
+    return dict(w_first=torch.cat(parts).contiguous(), b_first=b, first_scale=2.0 ** -(s_exp + 4),
+                real_cin=(64, 3) if pc else (64,))

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 3 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3 */
+#define CF_ABI_VERSION 4 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx */
 
 #define CF_OK 0
 #define CF_EINVAL (-22)
@@ -197,8 +197,23 @@ typedef struct cf_head_fused_args {
                                               64 (ks >> 1) + 16 (2 (ks & 1) + (j >> 2)) + 4 g + (j & 3); n_out <= 16; tail.w_hidden[][] ([16 tiles][8 k steps])
                                               and tail.w_out[] (one 16-row tile, natural k order) are 16x16x32 fragments too.  The launch
                                               then runs on the 16x16x32 patch kernel (1.14x the 32x32x16 rate under load) */
+  int32_t mx;                              /* layout3x3 && mfma16 only.  != 0: the FIRST layer runs as "fp16 main term + block-scaled FP6
+                                              cross terms" (v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4, 1.5 passes per
+                                              product instead of 3): src[0] is the 272-byte-per-pixel image cf_pack_feat_mx writes
+                                              (src_c[0] = 64), w_first[i] the operand stream of packing.pack_head_first_mx (slots / K_pad
+                                              are not read), src[1] (optional) the split-bf16 pc_hm planes as before; the tail layers are
+                                              unchanged.  ABI 4 */
+  float first_scale[CF_MAX_HEADS];         /* mx: 2^-(s+4) of head i's first layer (applied where b_first is added) */
 } cf_head_fused_args;
 int cf_head_fused(const cf_head_fused_args* a, void* stream);
+
+/* cf_pack_feat_mx: fp32 NHWC feature map [M][in_stride] (64 channels used) -> [M][272] bytes for cf_head_fused with mx = 1:
+ * per pixel [64 fp16 of clamp(16 x)][4 blocks of 32 B: FP6 e2m3 fields (element j in bits 6j..6j+5, 24 B used) of lo channels
+ * 0-31, lo 32-63, hi 0-31, hi 32-63, where hi = fp16(16 x), lo = 16 x - hi][4 E8M0 scale bytes in that order][12 B zero].
+ * A block's scale is 2^e with e the smallest integer such that max|.| <= 7.5 * 2^e.
+ * replaces: nothing in the reference - it is the operand preparation of model/networks/detectHeads.py:64-79 on this path
+ * (the fp32 -> split conversion the bf16x3 heads take from cf_split_bf16 / the DCN epilogue).  ABI 4 */
+int cf_pack_feat_mx(const float* x, int in_stride, void* rows, long M, void* stream);
 
 /* cf_dcn_v2_fused: modulated deformable 3x3 convolution (stride 1, pad 1, dil 1, groups 1) with
  * the bilinear gather fused into the GEMM A-tile staging, + bias(BN folded) + ReLU.

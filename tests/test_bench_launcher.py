@@ -50,10 +50,15 @@ def test_multi_rank_control_flow_rehearsal_bare_spawn():
     # every rank's own diagnostics (bench.StepClock): step time, host time to enqueue one step, wait on the exchange
     assert [r["rank"] for r in d["ranks"]] == [0, 1]
     for r in d["ranks"]:
-        assert set(r) == {"rank", "step_ms", "host_enqueue_ms", "host_enqueue_mean_ms", "gather_wait_ms", "gather_wait_host_ms"}
+        assert set(r) == {"rank", "step_ms", "host_enqueue_ms", "host_enqueue_mean_ms", "gather_wait_ms", "gather_wait_host_ms",
+                          "step_ms_p50", "step_ms_p95", "step_ms_max"}
+        assert 0 < r["step_ms_p50"] <= r["step_ms_p95"] <= r["step_ms_max"]
         assert r["step_ms"] > 0 and 0 < r["host_enqueue_ms"] <= r["host_enqueue_mean_ms"] and r["gather_wait_ms"] >= 0
         assert r["host_enqueue_mean_ms"] + r["gather_wait_host_ms"] <= r["step_ms"] * 1.5
     assert d["ms_per_step"] >= max(r["step_ms"] for r in d["ranks"]) - 1e-3        # the headline is the MAX over ranks
+    # the distribution of the timed steps (a median, not only a mean): MAX over ranks of each rank's figure
+    for k in ("step_ms_p50", "step_ms_p95", "step_ms_max"):
+        assert d[k] == max(r[k] for r in d["ranks"])
 
 
 def test_multi_rank_control_flow_rehearsal_under_the_drivers_launch_line():
