@@ -94,8 +94,8 @@ __device__ __forceinline__ void store_hidden_tile(unsigned char* xt, const f32x1
 // 64w + 16rt + 4(l >> 4) + r) of one 64-pixel half tile
 template <bool SCALED = false>
 __device__ __forceinline__ void store_hidden_tile16(unsigned char* xt, const f32x4 (&acc)[4][4], const float* bias,
-                                                    int wave, int lane, float sc = 1.0f) {
-  const int g = lane >> 4, c16 = lane & 15;
+                                                    int wave, int lane, float sc = 1.0f, int pxcol = -1) {
+  const int g = lane >> 4, c16 = pxcol < 0 ? (lane & 15) : pxcol;   // pxcol: the pixel column this lane's accumulators hold
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
     const int ch = wave * 64 + rt * 16 + 4 * g;
@@ -866,9 +866,10 @@ __global__ __launch_bounds__(256, 2) void head_patch_kernel(HeadPatchK q) {
 //
 // MX = true: the FIRST layer on "fp16 main term + block-scaled FP6 cross terms" (1.5 MFMA passes per product instead of the 3
 // of bf16x3; numerics and the gate that confines the scheme to the first layer: packing.pack_head_first_mx).  The
-// feature source is the 272-byte-per-pixel image cf_pack_feat_mx writes - [64 fp16 of 16 x][4 blocks of 32 FP6 e2m3 fields:
-// q6(xl) channels 0-31, 32-63, q6(xh) channels 0-31, 32-63; 32 B each, 24 used][one E8M0 scale byte per block][pad] - which IS
-// the LDS patch row.  Per tap: 2 k-steps of v_mfma_f32_16x16x32_f16 (weights' fp16 hi) and ONE v_mfma_scale_f32_16x16x128_f8f6f4
+// feature source is the 272-byte-per-pixel image cf_pack_feat_mx writes - four 64-byte segments g = 0..3, each [8 fp16: channels
+// 8g..8g+7 of 16 x][8 fp16: channels 32+8g..][32 FP6 e2m3 fields (24 B) + 8 B pad: block g of q6(xl) channels 0-31, 32-63,
+// q6(xh) channels 0-31, 32-63], then one E8M0 scale byte per block and padding - which IS the LDS patch row: lane group g of
+// every B fragment reads inside segment g (bank-conflict-free ds_read_b128, see colperm below).  Per tap: 2 k-steps of v_mfma_f32_16x16x32_f16 (weights' fp16 hi) and ONE v_mfma_scale_f32_16x16x128_f8f6f4
 // whose four 32-deep K blocks are q6(Wh) . q6(xl) (two 32-channel halves) and q6(Wl) . q6(xh): lane g = l >> 4 of either operand
 // holds K block g, with the block's scale byte in its lane.  Weights stream from L2 in (wave, tap) slabs, two items (of
 // main / main / cross) ahead.  pc_hm stays on bf16x3 with its weights pre-multiplied by 2^(s+4); the accumulators are scaled by
@@ -890,7 +891,14 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xt[];
   const HeadTailK& p = q.t;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: scalar weight tile addressing)
-  const int g = lane >> 4, c16 = lane & 15;
+  const int g = lane >> 4;
+  // MX, flat tile: lane l & 15 holds pixel COLUMN colperm(l & 15) of the 16-pixel tile row, not column l & 15.  A ds_read_b128 is
+  // served in groups of 16 lanes made of 8 lanes of one K group g and 8 of g + 1 ({0-3, 12-15, 20-27}, ...); with the K groups
+  // of a patch row 64 B apart and the row pitch = 16 B (mod 256 B), the 16 lanes of a group hit 16 different 16-byte bank
+  // quads iff the columns of lanes {4..11} form a set invariant under +4: {0,4,8,12,1,5,9,13} (the others get the rest).
+  const int c16 = (MX && !TP) ? ((lane & 12) == 4 || (lane & 12) == 8 ? (((lane & 15) - 4) & 3) * 4 + (((lane & 15) - 4) >> 2)
+                                                                      : (lane & 3) * 4 + 2 + ((lane & 15) >> 3))
+                              : (lane & 15);
   const int per_img = q.tiles_x * q.tiles_y;
   const int per_head = per_img * (p.M / p.HW);
   // grid = (head range, tile): a workgroup keeps its patch in LDS and walks q.hloop consecutive heads on it (heads
@@ -1006,11 +1014,28 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
       }
       sa = (int)__builtin_amdgcn_raw_buffer_load_b32(rs, l4, 14336, 0);
     };
-    // one half (tile rows 4 hf .. 4 hf + 3) of a main k-step / one quarter pair (tile rows 2 pr, 2 pr + 1) of a cross step
+    // one half (tile rows 4 hf .. 4 hf + 3) of a main k-step / one pair (tile rows 2 pr, 2 pr + 1) of a cross step
+#ifdef CF_MX_ARM_NOB       // dev timing arm (garbage results): the B fragments are read once, before the loop
+    hf16x8 xb_fix[4];
+    i32x8 xc_fix[2];
+    int sc_fix[2];
+    for (int ct = 0; ct < 4; ++ct) xb_fix[ct] = *reinterpret_cast<const hf16x8*>(xt + rowb[ct] + g * 64);
+    for (int c2 = 0; c2 < 2; ++c2) {
+      const unsigned char* r = xt + rowb[c2];
+      const u32x4 b0 = *reinterpret_cast<const u32x4*>(r + 64 * g + 32);
+      const u32x2 b1 = *reinterpret_cast<const u32x2*>(r + 64 * g + 48);
+      xc_fix[c2] = i32x8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], 0, 0};
+      sc_fix[c2] = (int)(*reinterpret_cast<const unsigned*>(r + 256) >> (8 * g));
+    }
+#endif
     auto main_half = [&](const hf16x8 (&A)[4], int off, int hf) {
       hf16x8 xb[4];
 #pragma unroll
+#ifdef CF_MX_ARM_NOB
+      for (int ct = 0; ct < 4; ++ct) xb[ct] = xb_fix[(ct + hf + off / 16) & 3];      // (rotating: the operands still change from MFMA to MFMA)
+#else
       for (int ct = 0; ct < 4; ++ct) xb[ct] = *reinterpret_cast<const hf16x8*>(xt + rowb[4 * hf + ct] + off);
+#endif
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -1023,10 +1048,14 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
 #pragma unroll
       for (int c2 = 0; c2 < 2; ++c2) {
         const unsigned char* r = xt + rowb[2 * pr + c2] + toff;
-        const u32x4 b0 = *reinterpret_cast<const u32x4*>(r + 128 + 32 * g);
-        const u32x2 b1 = *reinterpret_cast<const u32x2*>(r + 128 + 32 * g + 16);
+        const u32x4 b0 = *reinterpret_cast<const u32x4*>(r + 64 * g + 32);
+        const u32x2 b1 = *reinterpret_cast<const u32x2*>(r + 64 * g + 48);
         xb[c2] = i32x8{(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], 0, 0};
         sb[c2] = (int)(*reinterpret_cast<const unsigned*>(r + 256) >> (8 * g));     // this lane's block: byte g -> byte 0
+#ifdef CF_MX_ARM_NOB
+        xb[c2] = xc_fix[(c2 + pr) & 1];
+        sb[c2] = sc_fix[(c2 + pr) & 1];
+#endif
       }
 #define CF_MX_ROW(RT)                                                                                                   \
       {                                                                                                                 \
@@ -1043,23 +1072,30 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
     ldm(am[1], 0, 1);
     ldx(0);
     // Items per tap: main k-step 0, main k-step 1, cross.  The operands of the item two behind are requested in the MIDDLE
-    // of an item (its buffer was freed by the item before), with the only sched_barrier of the item right behind the
+    // of an item (their buffer was freed by the item before), with the only sched_barrier of the item right behind the
     // requests: they cannot sink to their first use, while the LDS reads of the NEXT item's first half may rise above the
-    // second half's MFMAs (an item is 32 MFMAs: a barrier at its end would expose an LDS round trip per item).
+    // second half's MFMAs.  (An explicit software pipeline of the B fragments - two buffers, one barrier per 16 MFMAs - was
+    // built and measured at the same time, 904 vs 897 us, for 16 more registers: docs/experiments/r5_heads_mx_kernel.md.)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int toff = ((tap / 3) * P_W + tap % 3) * ROWB;
-      main_half(am[0], toff + g * 16, 0);                  // channels 0-31: lane group g holds 8 g .. 8 g + 7
-      if (tap > 0) ldx(tap);                               // (cross operands of THIS tap: freed by the item before)
+      const int o0 = toff + g * 64, o1 = toff + g * 64 + 16;   // channels 0-31 / 32-63: lane group g holds 8 g .. 8 g + 7 of them
+#ifdef CF_MX_ARM_NOA       // dev timing arm (garbage results): no weight stream inside the loop
+#define CF_MX_LD(x)
+#else
+#define CF_MX_LD(x) x
+#endif
+      main_half(am[0], o0, 0);
+      if (tap > 0) CF_MX_LD(ldx(tap));                     // (cross operands of THIS tap: freed by the item before)
       __builtin_amdgcn_sched_barrier(0);
-      main_half(am[0], toff + g * 16, 1);
-      main_half(am[1], toff + 64 + g * 16, 0);             // channels 32-63
-      if (tap + 1 < 9) ldm(am[0], tap + 1, 0);
+      main_half(am[0], o0, 1);
+      main_half(am[1], o1, 0);
+      if (tap + 1 < 9) CF_MX_LD(ldm(am[0], tap + 1, 0));
       __builtin_amdgcn_sched_barrier(0);
-      main_half(am[1], toff + 64 + g * 16, 1);
+      main_half(am[1], o1, 1);
       cross_pair(toff, 0);
       cross_pair(toff, 1);
-      if (tap + 1 < 9) ldm(am[1], tap + 1, 1);
+      if (tap + 1 < 9) CF_MX_LD(ldm(am[1], tap + 1, 1));
       __builtin_amdgcn_sched_barrier(0);
       cross_pair(toff, 2);
       cross_pair(toff, 3);
@@ -1168,7 +1204,7 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) a2[rt][ct] = acc[rt][4 * half + ct];
-      store_hidden_tile16<MX>(xt, a2, q.b_first[head], wave, lane, MX ? q.first_scale[head] : 1.0f);
+      store_hidden_tile16<MX>(xt, a2, q.b_first[head], wave, lane, MX ? q.first_scale[head] : 1.0f, c16);
       if constexpr (MX) __builtin_amdgcn_sched_barrier(0);     // (the chain's first weight loads stay behind the tile stores)
       __syncthreads();
       head_tail_from_lds16(p, xt, head, TileMap{b, y0 + (64 >> TSH) * half, x0, q.H, q.W, TSH});
@@ -1210,7 +1246,15 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
         const u32x4 ph = {pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7])};
         const u32x4 pl = {pack2(v[0] - hi[0], v[1] - hi[1]), pack2(v[2] - hi[2], v[3] - hi[3]),
                           pack2(v[4] - hi[4], v[5] - hi[5]), pack2(v[6] - hi[6], v[7] - hi[7])};
+#ifdef CF_MX_ARM_NOCVT   // dev timing arm (garbage results): the accumulator bits as operands, no bias / ReLU / split arithmetic
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, acc[2 * s2][ct][0]), __builtin_bit_cast(unsigned, acc[2 * s2][ct][1]),
+                                                           __builtin_bit_cast(unsigned, acc[2 * s2][ct][2]), __builtin_bit_cast(unsigned, acc[2 * s2][ct][3])});
+        const bf16x8 xl = __builtin_bit_cast(bf16x8, u32x4{__builtin_bit_cast(unsigned, acc[2 * s2 + 1][ct][0]), __builtin_bit_cast(unsigned, acc[2 * s2 + 1][ct][1]),
+                                                           __builtin_bit_cast(unsigned, acc[2 * s2 + 1][ct][2]), __builtin_bit_cast(unsigned, acc[2 * s2 + 1][ct][3])});
+        (void)ph; (void)pl;
+#else
         const bf16x8 xh = __builtin_bit_cast(bf16x8, ph), xl = __builtin_bit_cast(bf16x8, pl);
+#endif
         oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, oacc[ct], 0, 0, 0);
         oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, oacc[ct], 0, 0, 0);
         oacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, oacc[ct], 0, 0, 0);
@@ -1218,6 +1262,15 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
     }
   }
   const int n_out = p.n_out[head], act = p.act[head];
+#ifdef CF_MX_ARM_NORED     // dev timing arm (garbage results): no partial-sum exchange, no barriers, one store per lane
+  {
+    float sum = 0.0f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) sum += (oacc[ct][0] + oacc[ct][1]) + (oacc[ct][2] + oacc[ct][3]);
+    if (sum == 12345.0f) p.out[head][tid] = sum;
+  }
+  continue;
+#endif
   float* red = reinterpret_cast<float*>(xt + hp16_patch_bytes(PC));   // [wave][n 16][px 128], BEHIND the patch (which the next head reuses)
 #pragma unroll
   for (int ct = 0; ct < 8; ++ct)
@@ -1297,15 +1350,14 @@ __global__ __launch_bounds__(256) void pack_feat_mx_kernel(const float* __restri
   asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(l6) : "v"(le), "v"(lo_), "v"(sl));
   unsigned char* row = rows + m * 272;
   {
-    u32x4* o = reinterpret_cast<u32x4*>(row + 64 * blk);
     const u32x4* hs = reinterpret_cast<const u32x4*>(&h);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = hs[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(row + 64 * i + 16 * blk) = hs[i];     // channels 32 blk + 8 i ..: segment i
   }
-  *reinterpret_cast<u32x4*>(row + 128 + 32 * blk) = u32x4{(unsigned)l6[0], (unsigned)l6[1], (unsigned)l6[2], (unsigned)l6[3]};
-  *reinterpret_cast<u32x4*>(row + 144 + 32 * blk) = u32x4{(unsigned)l6[4], (unsigned)l6[5], 0u, 0u};
-  *reinterpret_cast<u32x4*>(row + 192 + 32 * blk) = u32x4{(unsigned)h6[0], (unsigned)h6[1], (unsigned)h6[2], (unsigned)h6[3]};
-  *reinterpret_cast<u32x4*>(row + 208 + 32 * blk) = u32x4{(unsigned)h6[4], (unsigned)h6[5], 0u, 0u};
+  *reinterpret_cast<u32x4*>(row + 64 * blk + 32) = u32x4{(unsigned)l6[0], (unsigned)l6[1], (unsigned)l6[2], (unsigned)l6[3]};
+  *reinterpret_cast<u32x4*>(row + 64 * blk + 48) = u32x4{(unsigned)l6[4], (unsigned)l6[5], 0u, 0u};
+  *reinterpret_cast<u32x4*>(row + 64 * (2 + blk) + 32) = u32x4{(unsigned)h6[0], (unsigned)h6[1], (unsigned)h6[2], (unsigned)h6[3]};
+  *reinterpret_cast<u32x4*>(row + 64 * (2 + blk) + 48) = u32x4{(unsigned)h6[4], (unsigned)h6[5], 0u, 0u};
   row[256 + blk] = (unsigned char)(el + 127);
   row[258 + blk] = (unsigned char)(eh + 127);
   if (blk == 0) {

@@ -208,8 +208,9 @@ typedef struct cf_head_fused_args {
 int cf_head_fused(const cf_head_fused_args* a, void* stream);
 
 /* cf_pack_feat_mx: fp32 NHWC feature map [M][in_stride] (64 channels used) -> [M][272] bytes for cf_head_fused with mx = 1:
- * per pixel [64 fp16 of clamp(16 x)][4 blocks of 32 B: FP6 e2m3 fields (element j in bits 6j..6j+5, 24 B used) of lo channels
- * 0-31, lo 32-63, hi 0-31, hi 32-63, where hi = fp16(16 x), lo = 16 x - hi][4 E8M0 scale bytes in that order][12 B zero].
+ * per pixel four 64-byte segments g = 0..3 - [8 fp16: hi channels 8g..8g+7][8 fp16: hi channels 32+8g..32+8g+7][FP6 block g:
+ * 32 e2m3 fields (element j in bits 6j..6j+5, 24 B) + 8 B zero], block 0 / 1 = lo channels 0-31 / 32-63, block 2 / 3 = hi
+ * channels 0-31 / 32-63, where hi = fp16(clamp(16 x)), lo = 16 x - hi - then [4 E8M0 scale bytes, block order][12 B zero].
  * A block's scale is 2^e with e the smallest integer such that max|.| <= 7.5 * 2^e.
  * replaces: nothing in the reference - it is the operand preparation of model/networks/detectHeads.py:64-79 on this path
  * (the fp32 -> split conversion the bf16x3 heads take from cf_split_bf16 / the DCN epilogue).  ABI 4 */

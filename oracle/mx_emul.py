@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 ASCALE = 16.0
-ROW = 272        # bytes per pixel of the mx feature map: [64 fp16][xl6 blk0 | xl6 blk1 | xh6 blk0 | xh6 blk1: 32 B each, 24 used][4 scale bytes][pad]
+ROW = 272        # bytes per pixel of the mx feature map: 4 segments of [8 fp16 | 8 fp16 | 24 B of FP6 fields + 8 pad], 4 scale bytes, pad (feat_rows_ref)
 
 _E2M3 = np.array([(m / 8.0 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 1)) for e in range(4) for m in range(8)])
 
@@ -84,16 +84,38 @@ def feat_rows_ref(feat_nhwc):
     hi, lo = split_f16(x)
     M = x.shape[0]
     rows = np.zeros((M, ROW), np.uint8)
-    rows[:, :128] = np.ascontiguousarray(np.clip(x, -65504.0, 65504.0).astype(np.float16)).view(np.uint8).reshape(M, 128)
+    h16 = np.ascontiguousarray(np.clip(x, -65504.0, 65504.0).astype(np.float16)).view(np.uint8).reshape(M, 8, 16)   # 8-channel chunks
+    for g in range(4):                                         # segment g: chunk g (channels 8g..), chunk 4 + g (channels 32 + 8g..)
+        rows[:, 64 * g:64 * g + 16] = h16[:, g]
+        rows[:, 64 * g + 16:64 * g + 32] = h16[:, 4 + g]
     hc, he, _ = quant_blocks(hi)
     lc, le, _ = quant_blocks(lo)
     lf, hf = pack_fields(lc), pack_fields(hc)                  # (M, 2, 24)
     for blk in range(2):
-        rows[:, 128 + 32 * blk:128 + 32 * blk + 24] = lf[:, blk]
-        rows[:, 192 + 32 * blk:192 + 32 * blk + 24] = hf[:, blk]
+        rows[:, 64 * blk + 32:64 * blk + 56] = lf[:, blk]
+        rows[:, 64 * (2 + blk) + 32:64 * (2 + blk) + 56] = hf[:, blk]
         rows[:, 256 + blk] = (le[:, blk] + 127).astype(np.uint8)
         rows[:, 258 + blk] = (he[:, blk] + 127).astype(np.uint8)
     return rows
+
+
+def rows_unpack(rows):
+    """(M, ROW) uint8 -> (hi fp16 values (M, 64), q6(lo) (M, 64), q6(hi) (M, 64)) as float64: the row format read back"""
+    M = rows.shape[0]
+    hi = np.zeros((M, 64))
+    for g in range(4):
+        hi[:, 8 * g:8 * g + 8] = rows[:, 64 * g:64 * g + 16].copy().view(np.float16)
+        hi[:, 32 + 8 * g:40 + 8 * g] = rows[:, 64 * g + 16:64 * g + 32].copy().view(np.float16)
+    out = []
+    for first, sc in ((0, 256), (2, 258)):
+        q = np.zeros((M, 64))
+        for blk in range(2):
+            seg = rows[:, 64 * (first + blk) + 32:64 * (first + blk) + 56]
+            bits = [int.from_bytes(bytes(r), "little") for r in seg]
+            codes = np.array([[(b >> (6 * j)) & 63 for j in range(32)] for b in bits], np.uint8)
+            q[:, 32 * blk:32 * blk + 32] = e2m3_values(codes) * np.ldexp(1.0, rows[:, sc + blk].astype(np.int32) - 127)[:, None]
+        out.append(q)
+    return hi, out[0], out[1]
 
 
 def weight_scale_exp(w):

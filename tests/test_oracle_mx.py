@@ -45,15 +45,16 @@ def test_feature_rows_layout():
     x = np.abs(np.random.RandomState(1).standard_normal((7, 64)).astype(np.float32)) * 2
     rows = mx_emul.feat_rows_ref(x)
     assert rows.shape == (7, mx_emul.ROW) and mx_emul.ROW == packing.MX_ROW == 272
-    hi = rows[:, :128].copy().view(np.float16).astype(np.float32)
-    assert np.array_equal(hi, (x * 16).astype(np.float16).astype(np.float32))
-    assert not rows[:, 152:160].any() and not rows[:, 216:224].any() and not rows[:, 260:].any()      # padding is zero
-    # decode block 1 of the hi fields with its scale byte: equals the quantiser's value
-    bits = [int.from_bytes(bytes(r[224:248]), "little") for r in rows]
-    codes = np.array([[(b >> (6 * j)) & 63 for j in range(32)] for b in bits], np.uint8)
-    val = mx_emul.e2m3_values(codes) * np.ldexp(1.0, rows[:, 259].astype(np.int32) - 127)[:, None]
-    _, _, dq = mx_emul.quant_blocks(hi)
-    assert np.array_equal(val, dq[:, 32:])
+    hi, ql, qh = mx_emul.rows_unpack(rows)
+    h_ref, l_ref = mx_emul.split_f16(x * np.float32(16))
+    assert np.array_equal(hi, h_ref.astype(np.float64))
+    assert np.array_equal(qh, mx_emul.quant_blocks(h_ref)[2]) and np.array_equal(ql, mx_emul.quant_blocks(l_ref)[2])
+    # segment g of a row: channels 8g.. and 32 + 8g.. as fp16, then FP6 block g; padding is zero
+    assert np.array_equal(rows[:, 64:80].copy().view(np.float16).astype(np.float32), h_ref[:, 8:16])
+    assert np.array_equal(rows[:, 80:96].copy().view(np.float16).astype(np.float32), h_ref[:, 40:48])
+    for g in range(4):
+        assert not rows[:, 64 * g + 56:64 * g + 64].any()
+    assert not rows[:, 260:].any()
 
 
 def _decode_stream(w_first, pc):
@@ -104,16 +105,7 @@ def test_operand_stream_decodes_to_the_oracle_arithmetic():
     assert d["w_first"].numel() == 4 * 9 * packing.MX_SLAB + 4 * 3 * 4 * 2048
     wh, wh6, wl6, wp = _decode_stream(d["w_first"], True)
     rows = mx_emul.feat_rows_ref(feat.permute(0, 2, 3, 1).reshape(-1, 64).numpy())
-    xh = rows[:, :128].copy().view(np.float16).astype(np.float64).reshape(5, 6, 64)
-    def fields(lo, sc):
-        out = np.zeros((rows.shape[0], 64))
-        for blk in range(2):
-            for r in range(rows.shape[0]):
-                bits = int.from_bytes(bytes(rows[r, lo + 32 * blk:lo + 32 * blk + 24]), "little")
-                codes = np.array([(bits >> (6 * j)) & 63 for j in range(32)], np.uint8)
-                out[r, 32 * blk:32 * blk + 32] = mx_emul.e2m3_values(codes) * np.ldexp(1.0, int(rows[r, sc + blk]) - 127)
-        return out.reshape(5, 6, 64)
-    xl6, xh6 = fields(128, 256), fields(192, 258)
+    xh, xl6, xh6 = (a.reshape(5, 6, 64) for a in mx_emul.rows_unpack(rows))
     pad = lambda a: np.pad(a, ((1, 1), (1, 1), (0, 0)))
     xhp, xl6p, xh6p = pad(xh), pad(xl6), pad(xh6)
     ph = pch[0].permute(1, 2, 0).to(torch.bfloat16).double().numpy()
