@@ -254,10 +254,14 @@ struct DcnF {
   int mask_activated;    // offmask channels 18..26 are modulation factors already (no sigmoid here)
 };
 
-template <int WC, int WP, int RT, bool COAL>
+// CT = 32-pixel column tiles per wave: 2 (64 pixels per wave), or 1 - half-size pixel tiles: half the accumulators and half the corner
+// registers per thread, half the LDS: three workgroups per CU instead of two where a wave's chain has nothing to hide behind.
+template <int WC, int WP, int RT, bool COAL, int CT = 2>
 __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   static_assert(WC * WP == 4, "4 waves per workgroup");
-  constexpr int PXB = 64 * WP;
+  static_assert(CT == 2 || (CT == 1 && WP == 2), "half-size tiles: two pixel groups of 32");
+  constexpr int PXB = 32 * CT * WP;
+  constexpr int NP = PXB * 4 / 256;          // (pixel, 8-channel unit) pairs per thread and chunk
   constexpr int PLANE = PXB * FROWB;
   constexpr int BUF = 2 * PLANE;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF + PXB * 9 * 32];
@@ -291,6 +295,14 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   //  instead of one per descriptor - it was 13 % of a 64-channel layer's workgroup time)
   constexpr int NDI = (PXB * 9 + 255) / 256;
   float omy[NDI], omx[NDI], omm[NDI];
+#ifdef CF_DCN_NODESC        // (dev timing experiment: no descriptor phase - every sample is the pixel's own cell with weight 1, 0, 0, 0)
+  for (int i = tid; i < PXB * 9; i += 256) {
+    const int m = min(m0 + i / 9, p.M - 1);
+    desc[2 * i] = f32x4{__int_as_float(m * p.C), __int_as_float(0), __int_as_float(0), ASCALE};
+    desc[2 * i + 1] = f32x4{1.0f, 0.0f, 0.0f, 0.0f};
+  }
+  if (false)
+#endif
 #pragma unroll
   for (int it = 0; it < NDI; ++it) {
     const int i = min(tid + 256 * it, PXB * 9 - 1);
@@ -300,6 +312,9 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     omx[it] = om[2 * tap + 1];
     omm[it] = om[18 + tap];
   }
+#ifdef CF_DCN_NODESC
+  if (false)
+#endif
 #pragma unroll
   for (int it = 0; it < NDI; ++it) {
     const int i = tid + 256 * it;
@@ -344,10 +359,10 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   //  step or spills and measured slower)
   constexpr bool DEEP = WP == 2;
   constexpr int NSET = DEEP ? 2 : 1;
-  f32x4 cvs[NSET][WP][4][2];   // 4 corners x 8 channels
-  f32x4 cws[NSET][WP];         // corner weights
-  float cmks[NSET][WP];        // 16 * sigmoid(mask)
-  auto load_b_pair = [&](int c, int i, f32x4 (&cv)[WP][4][2], f32x4 (&cw)[WP], float (&cmk)[WP]) __attribute__((always_inline)) {
+  f32x4 cvs[NSET][NP][4][2];   // 4 corners x 8 channels
+  f32x4 cws[NSET][NP];         // corner weights
+  float cmks[NSET][NP];        // 16 * sigmoid(mask)
+  auto load_b_pair = [&](int c, int i, f32x4 (&cv)[NP][4][2], f32x4 (&cw)[NP], float (&cmk)[NP]) __attribute__((always_inline)) {
     const int tap = c / p.chunks_per_tap;
     const int c0 = (c - tap * p.chunks_per_tap) * 32 + (tid & 3) * 8;
     {
@@ -376,13 +391,13 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
       cv[i][3][1] = *reinterpret_cast<const f32x4*>(a3 + 4);
     }
   };
-  auto load_b = [&](int c, f32x4 (&cv)[WP][4][2], f32x4 (&cw)[WP], float (&cmk)[WP]) {
+  auto load_b = [&](int c, f32x4 (&cv)[NP][4][2], f32x4 (&cw)[NP], float (&cmk)[NP]) {
 #pragma unroll
-    for (int i = 0; i < WP; ++i) load_b_pair(c, i, cv, cw, cmk);
+    for (int i = 0; i < NP; ++i) load_b_pair(c, i, cv, cw, cmk);
   };
-  auto store_b = [&](unsigned char* buf, const f32x4 (&cv)[WP][4][2], const f32x4 (&cw)[WP], const float (&cmk)[WP]) {
+  auto store_b = [&](unsigned char* buf, const f32x4 (&cv)[NP][4][2], const f32x4 (&cw)[NP], const float (&cmk)[NP]) {
 #pragma unroll
-    for (int i = 0; i < WP; ++i) {
+    for (int i = 0; i < NP; ++i) {
       const int pr = tid + 256 * i;
       const float mk = cmk[i];   // the mask (x 2^4 activation scale) is applied after the 4-corner sum, as the reference does
 #ifdef CF_DCN_NOBLEND       // (dev timing experiment: no blend / split arithmetic, the first corner's bits are staged as they are)
@@ -414,11 +429,11 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     }
   };
 
-  f32x16 accm[RT][2], accs[RT][2];
+  f32x16 accm[RT][CT], accs[RT][CT];
 #pragma unroll
   for (int a = 0; a < RT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < CT; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         accm[a][b][r] = 0.0f;
@@ -433,17 +448,26 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     }
   };
   auto mma_kstep = [&](const unsigned char* buf, int s, const f16x8 (&ah)[RT], const f16x8 (&al)[RT]) {
-    f16x8 xh[2], xl[2];
+    f16x8 xh[CT], xl[CT];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const unsigned char* row = buf + (wp * 64 + ct * 32 + li) * FROWB + s * 32 + h * 16;
+    for (int ct = 0; ct < CT; ++ct) {
+      const unsigned char* row = buf + (wp * 32 * CT + ct * 32 + li) * FROWB + s * 32 + h * 16;
       xh[ct] = *reinterpret_cast<const f16x8*>(row);
       xl[ct] = *reinterpret_cast<const f16x8*>(row + PLANE);
     }
+#ifdef CF_DCN_NOMFMA       // (dev timing experiment: ONE MFMA per k-step that still consumes every operand register)
+    {
+      f16x8 a = al[0] + ah[0], b = xh[0] + xl[0] + xh[CT - 1] + xl[CT - 1];
+#pragma unroll
+      for (int rt = 1; rt < RT; ++rt) a += al[rt] + ah[rt];
+      accm[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, accm[0][0], 0, 0, 0);
+      return;
+    }
+#endif
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+      for (int ct = 0; ct < CT; ++ct) {
         accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rt], xh[ct], accs[rt][ct], 0, 0, 0);
         accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rt], xl[ct], accs[rt][ct], 0, 0, 0);
         accm[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rt], xh[ct], accm[rt][ct], 0, 0, 0);
@@ -465,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   __syncthreads();
   // (an earlier form with exec-masked corner loads inside a pinned loop glitched when launched behind unrelated kernels,
   //  tools/stress_dcn.py: the loads below are unconditional)
-  auto iteration = [&](int j, f32x4 (&cv)[WP][4][2], f32x4 (&cw)[WP], float (&cmk)[WP]) {
+  auto iteration = [&](int j, f32x4 (&cv)[NP][4][2], f32x4 (&cw)[NP], float (&cmk)[NP]) {
     // MFMAs of chunk j; then chunk j+1 (held in set cv) is blended into the other buffer and the set is
     // re-requested for chunk j+1+NSET
     unsigned char* cur = smem + (j & 1) * BUF;
@@ -480,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     // of the 64-channel layers LOSE with it (254 vs 212 us, 149 vs 131 us: every wait for a corner or an LDS fragment then
     // also holds back the wave's next MFMA), so they keep the compiler's order.  CF_DCN_NOPIN: dev A/B.
 #ifndef CF_DCN_NOPIN
-    if constexpr (WP == 1)
+    if constexpr (WP == 1 && CT == 2)
     {
       f32x4 bv[2];                           // blended 8 channels of the pair in progress
       u32x4 bhi, blo;
@@ -512,10 +536,10 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
         }
       };
       auto kstep = [&](int s, const f16x8 (&ah)[RT], const f16x8 (&al)[RT]) __attribute__((always_inline)) {
-        f16x8 xh[2], xl[2];
+        f16x8 xh[CT], xl[CT];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          const unsigned char* row = cur + (wp * 64 + ct * 32 + li) * FROWB + s * 32 + h * 16;
+        for (int ct = 0; ct < CT; ++ct) {
+          const unsigned char* row = cur + (wp * 32 * CT + ct * 32 + li) * FROWB + s * 32 + h * 16;
           xh[ct] = *reinterpret_cast<const f16x8*>(row);
           xl[ct] = *reinterpret_cast<const f16x8*>(row + PLANE);
         }
@@ -523,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
+          for (int ct = 0; ct < CT; ++ct) {
             accs[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rt], xh[ct], accs[rt][ct], 0, 0, 0);
             work(slot++);
             __builtin_amdgcn_sched_barrier(0);
@@ -573,8 +597,8 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   if (gridDim.z > 1) {   // raw partial sums; scale / bias / activation happen in the reduction
     const int ns = p.n_rt * 32;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int m = m0 + wp * 64 + ct * 32 + li;
+    for (int ct = 0; ct < CT; ++ct) {
+      const int m = m0 + wp * 32 * CT + ct * 32 + li;
       if (m >= p.M || !w_ok) continue;
       float* o = p.partial + ((size_t)blockIdx.z * p.M + m) * ns;
 #pragma unroll
@@ -594,6 +618,19 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   // LDS tile (free after the loop's last barrier) and writes whole pixel rows - RT*128 contiguous bytes per pixel
   // instead of 32-byte pieces - and the split-bf16 copy as 8-byte pieces that are contiguous across lanes.
   constexpr bool coalesced = COAL;        // (the host selects it: N % 4 == 0)
+#ifdef CF_DCN_NOEPI         // (dev timing experiment: no output transposition / stores - one conditional store keeps the sums alive)
+  {
+    float sum = 0.0f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += accm[rt][ct][r] + accs[rt][ct][r];
+    if (sum == 12345.0f) p.out[tid] = sum;
+    return;
+  }
+#endif
   if (coalesced && w_ok) {
     constexpr int EROW = RT * 128 + 16;
     constexpr int LPP = RT * 8, PPI = 64 / LPP;
@@ -605,7 +642,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
     f32x4 bias4 = {0.0f, 0.0f, 0.0f, 0.0f};
     if (n_ok) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
       if (ct) cf_wave_lds_sync();            // ... and every lane has read the previous tile before it is overwritten
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -620,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
 #pragma unroll
       for (int it = 0; it < 32 / PPI; ++it) {
         const int ploc = it * PPI + psub;
-        const size_t m = (size_t)m0 + wp * 64 + ct * 32 + ploc;
+        const size_t m = (size_t)m0 + wp * 32 * CT + ct * 32 + ploc;
         f32x4 v = *reinterpret_cast<const f32x4*>(eb + ploc * EROW + chunk * 16) + bias4;
         if (n_ok && m < (size_t)p.M) {
           if (p.act == CF_ACT_RELU) {
@@ -647,8 +684,8 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   }
 
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    const int m = m0 + wp * 64 + ct * 32 + li;
+  for (int ct = 0; ct < CT; ++ct) {
+    const int m = m0 + wp * 32 * CT + ct * 32 + li;
     if (coalesced) break;
     if (m >= p.M) continue;
 #pragma unroll
@@ -820,11 +857,25 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   // four channel-group waves idle in the MFMAs, all four staging) while that launch still fits the chip in one round:
   // 128 -> 64 at 56x100, bs=1: 30.4 vs 43.4 us, bs=2: 31.6 vs 45.0 us; at 350 workgroups the gain is gone.  Same K order,
   // same K split: bit-identical, so the choice may depend on the batch size (as in cf_conv3x3_f16x3).
+#ifdef CF_DCN_SMALLTILE     // (dev timing experiment: the 64-pixel-tile configuration at every grid size)
+  if (a->N_pad <= 64) {
+#else
   if (a->N_pad <= 64 && (M + 63) / 64 * (long)ks <= 256) {
+#endif
     const dim3 grid((unsigned)((M + 63) / 64), 1u, ks);
     if (coal) launch_f16(dcn_f16x3_kernel<4, 1, 1, true>, grid, 0, st, k);
     else launch_f16(dcn_f16x3_kernel<4, 1, 1, false>, grid, 0, st, k);
   } else if (a->N_pad <= 64) {          // 64 channels: 2 x 32-channel wave rows, 2 x 64 pixels
+    // half-size pixel tiles (32 pixels per wave: 156 registers, 39 KB of LDS - three workgroups per CU instead of two): the parts
+    // of this kernel add up instead of overlapping (docs/experiments/r5_dcn_attribution.md), so a third wave per SIMD pays
+    // wherever the grid is not many rounds deep - 8 x 64 -> 64 at 112 x 200: 116.5 vs 123.5 us, 8 x 128 -> 64 at 56 x 100: 61.1 vs
+    // 72.6 us, 16 x 64 -> 64 at 112 x 200: equal; step 7.75 vs 7.80 ms.  Same K order: bit-identical.  CF_DCN_CT1=0: dev A/B.
+    static const int ct1 = [] { const char* e = getenv("CF_DCN_CT1"); return e ? atoi(e) : 1; }();
+    if (ct1 && coal) {
+      const dim3 grid1((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 63) / 64), ks);
+      launch_f16(dcn_f16x3_kernel<2, 2, 1, true, 1>, grid1, 0, st, k);
+      return cf_check_launch("cf_dcn_v2_f16x3");
+    }
     const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((a->N_pad + 63) / 64), ks);
     if (coal) launch_f16(dcn_f16x3_kernel<2, 2, 1, true>, grid, 0, st, k);
     else launch_f16(dcn_f16x3_kernel<2, 2, 1, false>, grid, 0, st, k);
