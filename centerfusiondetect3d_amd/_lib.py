@@ -30,7 +30,7 @@ class DcnArgs(C.Structure):
                 ("N", C.c_int32), ("N_pad", C.c_int32), ("out", _f), ("out_stride", C.c_int32),
                 ("act", C.c_int32), ("precise", C.c_int32), ("out_scale", C.c_float),
                 ("out_split_bf16", _f), ("split_stride", C.c_int32), ("workspace", _f),
-                ("workspace_bytes", C.c_size_t), ("mask_activated", C.c_int32)]
+                ("workspace_bytes", C.c_size_t), ("mask_activated", C.c_int32), ("out_mx", _f)]
 
 
 CF_MAX_HEADS = 12

@@ -23,6 +23,7 @@
 // per register group, so the fp32 NHWC store is one 16-byte write per lane and group.
 #include <stdlib.h>
 #include "cf_f16x3.h"
+#include "cf_mx.h"
 
 namespace {
 
@@ -249,6 +250,7 @@ struct DcnF {
   float out_scale;
   unsigned* out_split;   // optional split-bf16 copy [M][2][split_stride] (as 32-bit words: 2 bf16 each)
   int split_stride;
+  unsigned char* out_mx; // optional mx rows [M][272] (cf_pack_feat_mx's format; N = 64, one 32-channel row tile per wave)
   float* partial;        // K split (gridDim.z > 1): raw partial sums [z][M][n_rt * 32], reduced by dcn_reduce_kernel
   int direct_epilogue;   // dev A/B (CF_DCN_EPI=0): store the accumulators directly
   int mask_activated;    // offmask channels 18..26 are modulation factors already (no sigmoid here)
@@ -680,6 +682,23 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
           }
         }
       }
+      if constexpr (RT == 1) {
+        // the mx rows of the heads (cf_head_fused mx = 1) from the same tile: this wave holds one 32-channel block of its 32
+        // pixels; lane l < 32 packs pixel l exactly as cf_pack_feat_mx would from `out` (same fp32 values: tile + bias, ReLU)
+        if (p.out_mx && lane < 32) {
+          const size_t m = (size_t)m0 + wp * 32 * CT + ct * 32 + lane;
+          if (m < (size_t)p.M) {
+            float v[32];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              f32x4 t = *reinterpret_cast<const f32x4*>(eb + lane * EROW + i * 16) + *reinterpret_cast<const f32x4*>(p.bias + rt0 * 32 + 4 * i);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[4 * i + e] = p.act == CF_ACT_RELU ? fmaxf(t[e], 0.0f) : t[e];
+            }
+            mx_pack_block(v, p.out_mx + m * 272, rt0);
+          }
+        }
+      }
     }
   }
 
@@ -839,13 +858,16 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   k.out_scale = a->out_scale;
   k.out_split = static_cast<unsigned*>(a->out_split_bf16);
   k.split_stride = a->split_stride;
+  k.out_mx = static_cast<unsigned char*>(a->out_mx);
+  CF_REQUIRE(!a->out_mx || (a->N == 64 && a->N_pad == 64 && (a->N & 3) == 0),
+             "cf_dcn_v2_f16x3: the mx output is the 64-channel feature map's (N = N_pad = 64)");
   CF_REQUIRE(!a->out_split_bf16 || (a->split_stride >= a->N && a->split_stride % 8 == 0 && a->N % 4 == 0),
              "cf_dcn_v2_f16x3: split output needs N %% 4 == 0 and a plane stride >= N that is a multiple of 8");
   hipStream_t st = (hipStream_t)stream;
   // K split for small maps, when the caller provides the workspace (decided per image geometry, never
   // by the batch size: it changes the summation order, and a shard has to reproduce the full batch)
   const unsigned ks = a->workspace ? (unsigned)dcn_k_split(a->H, a->W, k.n_chunks, a->N_pad) : 1u;
-  CF_REQUIRE(ks == 1 || !a->out_split_bf16, "cf_dcn_v2_f16x3: the split-bf16 output is not available on K-split maps");
+  CF_REQUIRE(ks == 1 || (!a->out_split_bf16 && !a->out_mx), "cf_dcn_v2_f16x3: the split-bf16 / mx outputs are not available on K-split maps");
   CF_REQUIRE(ks == 1 || a->workspace_bytes >= (size_t)ks * M * a->N_pad * sizeof(float),
              "cf_dcn_v2_f16x3: workspace of %zu bytes is smaller than cf_dcn_v2_workspace_bytes(...)", a->workspace_bytes);
   k.partial = static_cast<float*>(a->workspace);

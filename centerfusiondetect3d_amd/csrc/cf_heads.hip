@@ -17,6 +17,7 @@
 // the output layer the 4 waves split K instead and their partial sums are reduced through LDS.
 #include <stdlib.h>
 #include "cf_common.h"
+#include "cf_mx.h"
 
 namespace {
 
@@ -1305,16 +1306,8 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
 
 // ---------------------------------------------------------------------------------------------
 // fp32 NHWC feature map -> the 272-byte mx rows head_patch16_kernel<.., MX> stages (layout: there).  One thread per
-// (pixel, 32-channel block): v = clamp(16 x), hi = fp16(v), lo = v - hi (exact); block exponent = smallest e with
-// max|.| <= 7.5 * 2^e, from the bits of the maximum (exponent field - 2, + 1 if the mantissa exceeds 1.875); fields by
-// v_cvt_scalef32_pk32_fp6_f16 / v_cvt_scalef32_2xpk16_fp6_f32 (RNE, field j = channel j).
+// (pixel, 32-channel block); the arithmetic is cf_mx.h: mx_pack_block (shared with the DCN epilogue).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int mx_block_exp(float amax) {   // amax >= 0
-  const int bits = __builtin_bit_cast(int, amax);
-  const int e = ((bits >> 23) & 0xff) - 127 - 2 + ((bits & 0x7fffff) > 0x700000 ? 1 : 0);
-  return amax == 0.0f ? -127 : e;
-}
-
 __global__ __launch_bounds__(256) void pack_feat_mx_kernel(const float* __restrict__ x, int in_stride,
                                                            unsigned char* __restrict__ rows, long M) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1322,48 +1315,14 @@ __global__ __launch_bounds__(256) void pack_feat_mx_kernel(const float* __restri
   const int blk = (int)(t & 1);
   if (m >= M) return;
   const f32x4* src = reinterpret_cast<const f32x4*>(x + m * in_stride + 32 * blk);
-  f32x4 q[8];
+  float v[32];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) q[i] = src[i];
-  hf16x32 h;
-  f32x16 le, lo_;                              // lo: even / odd channels (the f32 convert interleaves its two sources)
-  float mh = 0.0f, ml = 0.0f;
+  for (int i = 0; i < 8; ++i) {
+    const f32x4 q = src[i];
 #pragma unroll
-  for (int j = 0; j < 32; ++j) {
-    const float v = __builtin_amdgcn_fmed3f(q[j >> 2][j & 3] * 16.0f, -65504.0f, 65504.0f);
-    const _Float16 hj = (_Float16)v;
-    const float l = v - (float)hj;
-    h[j] = hj;
-    if (j & 1) lo_[j >> 1] = l; else le[j >> 1] = l;
-    mh = fmaxf(mh, fabsf((float)hj));
-    ml = fmaxf(ml, fabsf(l));
+    for (int e = 0; e < 4; ++e) v[4 * i + e] = q[e];
   }
-  const int eh = mx_block_exp(mh), el = mx_block_exp(ml);
-  // (a block of zeros converts with scale 1: 0 / 2^-127 would do as well, this keeps the divide away from the edge)
-  const float sh = mh == 0.0f ? 1.0f : __builtin_bit_cast(float, (eh + 127) << 23);
-  const float sl = ml == 0.0f ? 1.0f : __builtin_bit_cast(float, (el + 127) << 23);
-  // inline asm with an early-clobber destination: hipcc (ROCm 7.2) may allocate the 6-dword result ON TOP of the scale
-  // (or a source) register of the builtin form, and the instruction writes its result in passes while still reading them
-  // - every field behind the first pair then converts with a clobbered scale (seen: v_cvt_... v[0:5], .., .., v0)
-  i32x6 h6, l6;
-  asm volatile("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(h6) : "v"(h), "v"(sh));
-  asm volatile("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(l6) : "v"(le), "v"(lo_), "v"(sl));
-  unsigned char* row = rows + m * 272;
-  {
-    const u32x4* hs = reinterpret_cast<const u32x4*>(&h);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(row + 64 * i + 16 * blk) = hs[i];     // channels 32 blk + 8 i ..: segment i
-  }
-  *reinterpret_cast<u32x4*>(row + 64 * blk + 32) = u32x4{(unsigned)l6[0], (unsigned)l6[1], (unsigned)l6[2], (unsigned)l6[3]};
-  *reinterpret_cast<u32x4*>(row + 64 * blk + 48) = u32x4{(unsigned)l6[4], (unsigned)l6[5], 0u, 0u};
-  *reinterpret_cast<u32x4*>(row + 64 * (2 + blk) + 32) = u32x4{(unsigned)h6[0], (unsigned)h6[1], (unsigned)h6[2], (unsigned)h6[3]};
-  *reinterpret_cast<u32x4*>(row + 64 * (2 + blk) + 48) = u32x4{(unsigned)h6[4], (unsigned)h6[5], 0u, 0u};
-  row[256 + blk] = (unsigned char)(el + 127);
-  row[258 + blk] = (unsigned char)(eh + 127);
-  if (blk == 0) {
-    *reinterpret_cast<unsigned*>(row + 260) = 0u;
-    *reinterpret_cast<u32x2*>(row + 264) = u32x2{0u, 0u};
-  }
+  mx_pack_block(v, rows + m * 272, blk);
 }
 
 }  // namespace

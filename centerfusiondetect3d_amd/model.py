@@ -452,8 +452,16 @@ class _Plan:
                 # fp32 feature map of this (sub-)batch
                 if feat_in is None:
                     feat_in = buf(B, h4, w4, packing.MX_ROW, dtype=torch.uint8)
-                self.step_index["feat.pack_mx"] = len(self.steps)
-                self.add_step((self.lib.cf_pack_feat_mx, feat.data_ptr(), 64, feat_in.data_ptr(), C.c_long(B * h4 * w4)))
+                # ... written by the epilogue of the DCN that produces the map (f16x3 kernel, no K split at this size); a
+                # separate pass over the fp32 map only if that kernel is not in use
+                producer = [a for a in self.keep if isinstance(a, _lib.DcnArgs) and a.out == feat.data_ptr()
+                            and a.out_scale > 0 and a.N == 64 and a.N_pad == 64]
+                if producer and bool(getattr(model, "pack_mx_fused", True)):
+                    producer[-1].out_mx = feat_in.data_ptr()
+                    producer[-1].workspace = None          # (the mx output and a K-split reduction exclude each other)
+                else:
+                    self.step_index["feat.pack_mx"] = len(self.steps)
+                    self.add_step((self.lib.cf_pack_feat_mx, feat.data_ptr(), 64, feat_in.data_ptr(), C.c_long(B * h4 * w4)))
             elif bf:
                 # the split-bf16 copy of the feature map the heads read is written by the epilogue of the DCN
                 # that produces it (f16x3 kernel); a separate split pass only if that kernel is not in use

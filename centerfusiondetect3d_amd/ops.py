@@ -207,7 +207,7 @@ def run_head_tail(a):
 
 
 def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act=ACT_RELU,
-             precise=True, out_split=None, workspace=None):
+             precise=True, out_split=None, workspace=None, out_mx=None):
     a = _lib.DcnArgs()
     a.x, a.offmask, a.om_stride = x.data_ptr(), offmask.data_ptr(), om_stride
     a.B, a.H, a.W, a.C = B, H, W, pd.c
@@ -217,6 +217,8 @@ def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act
     a.out_scale = float(getattr(pd, "out_scale", 0.0))
     if out_split is not None:            # (B,H,W,2,Cs) bf16: split copy for the head kernels (f16x3 kernel only)
         a.out_split_bf16, a.split_stride = out_split.data_ptr(), out_split.shape[-1]
+    if out_mx is not None:               # (B,H,W,272) uint8: the mx rows of the heads' first layer (f16x3 kernel, N = 64)
+        a.out_mx = out_mx.data_ptr()
     if workspace is not None:            # K split on small maps (cf_dcn_v2_workspace_bytes)
         a.workspace = workspace.data_ptr()
         a.workspace_bytes = workspace.numel() * workspace.element_size()

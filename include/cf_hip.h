@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 4 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx */
+#define CF_ABI_VERSION 4 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx, cf_dcn_args.out_mx */
 
 #define CF_OK 0
 #define CF_EINVAL (-22)
@@ -245,6 +245,9 @@ typedef struct cf_dcn_args {
   int32_t mask_activated; /* 0: offmask channels 18..26 are mask LOGITS, sigmoid applied here (the fused DeformConv of
                              the module path); != 0: they already are the modulation factors, used as they are - the
                              contract of torchvision.ops.deform_conv2d(mask=...) (dla.py:460: the caller's sigmoid) */
+  void* out_mx;           /* cf_dcn_v2_f16x3 only, optional, N = N_pad = 64, not on K-split maps: the same result additionally
+                             as the [B*H*W][272] byte rows of cf_pack_feat_mx (bit-identical to packing `out`): the operand
+                             format of cf_head_fused with mx = 1 - saves that pass over the feature map.  ABI 4 */
 } cf_dcn_args;
 int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream);
 

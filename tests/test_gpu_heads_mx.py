@@ -144,3 +144,26 @@ def test_head_fused_mx_refuses_what_it_cannot_read(dev):
     f, heads, _, _ = _heads_case(dev, 1, False, 1, 8, 16, n_outs=(3,), acts=(0,))
     with pytest.raises(_lib.CfHipError, match="pc_hm"):
         ops.run_head_fused(f)
+
+
+def test_dcn_epilogue_writes_the_same_mx_rows(dev):
+    """cf_dcn_v2_f16x3 with out_mx: the rows the DCN's epilogue writes are, byte for byte, what cf_pack_feat_mx makes of the
+    layer's fp32 output (and so the oracle's rows of it) - on both tile sizes of the 64-channel kernel, ragged last tile"""
+    import os
+    from centerfusiondetect3d_amd import ops, packing
+    for (B, H, W) in ((2, 23, 37), (1, 8, 16)):
+        g = torch.Generator().manual_seed(B)
+        x = torch.randn(B, H, W, 64, generator=g).to(dev)
+        om = torch.zeros(B, H, W, 32)
+        om[..., :18] = torch.randn(B, H, W, 18, generator=g) * 1.5
+        om[..., 18:27] = torch.randn(B, H, W, 9, generator=g)
+        om = om.to(dev)
+        pd = packing.pack_dcn_f16(torch.randn(64, 64, 3, 3, generator=g) * 0.05, torch.randn(64, generator=g) * 0.1).to(dev)
+        out = torch.empty(B, H, W, 64, device=dev)
+        rows = torch.zeros(B, H, W, 272, device=dev, dtype=torch.uint8)
+        a = ops.dcn_args(pd, x, om, 32, B, H, W, out, 64, out_mx=rows)
+        ops.run_dcn(a)
+        ref_rows = ops.pack_feat_mx(out)
+        assert torch.equal(rows, ref_rows)
+        assert np.array_equal(rows.view(-1, 272).cpu().numpy(), mx_emul.feat_rows_ref(out.view(-1, 64).cpu().numpy()))
+        assert float(out.abs().max()) > 0 and bool((out >= 0).all())            # ReLU applied, not a dead layer
