@@ -558,6 +558,9 @@ def main():
     ap.add_argument("--heads-bf16x3", action="store_true",
                     help="A/B: the heads' first layers on bf16x3 (3 MFMA passes per product, the round-4 arithmetic) instead of "
                          "fp16 main term + block-scaled FP6 cross terms (1.5 passes; model.heads_mx)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="experiment (never the default line): consecutive steps alternate over this many caller streams, so the "
+                         "heads of step i may run beside the backbone of step i+1 (one plan set per stream)")
     ap.add_argument("--force-collective", action="store_true",
                     help="initialise the RCCL process group and issue the per-step all-gather also at world size 1 (what a "
                          "rank of an N-GPU run does, on a one-GPU box)")
@@ -634,7 +637,17 @@ def main():
     pending = []
     clock = StepClock(dev)
 
+    flight = [torch.cuda.Stream(dev) for _ in range(args.in_flight)] if args.in_flight > 1 else None
+    n_step = [0]
+
     def launches():
+        if flight is not None:
+            with torch.cuda.stream(flight[n_step[0] % len(flight)]):
+                n_step[0] += 1
+                out = model(images, pc_dep=pc_dep, calib=calib)
+                post = decode_post_packed(out, calib, tinv, (H // 4, W // 4), 100)
+                pending.append(gatherer.submit(post))
+            return
         out = model(images, pc_dep=pc_dep, calib=calib)
         post = decode_post_packed(out, calib, tinv, (H // 4, W // 4), 100)
         pending.append(gatherer.submit(post))

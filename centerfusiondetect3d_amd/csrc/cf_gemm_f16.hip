@@ -893,13 +893,10 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
     // wherever the grid is not many rounds deep - 8 x 64 -> 64 at 112 x 200: 116.5 vs 123.5 us, 8 x 128 -> 64 at 56 x 100: 61.1 vs
     // 72.6 us, 16 x 64 -> 64 at 112 x 200: equal; step 7.75 vs 7.80 ms.  Same K order: bit-identical.  CF_DCN_CT1=0: dev A/B.
     static const int ct1 = [] { const char* e = getenv("CF_DCN_CT1"); return e ? atoi(e) : 1; }();
-    if (ct1 && coal) {
-      const dim3 grid1((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 63) / 64), ks);
-      launch_f16(dcn_f16x3_kernel<2, 2, 1, true, 1>, grid1, 0, st, k);
-      return cf_check_launch("cf_dcn_v2_f16x3");
-    }
     const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((a->N_pad + 63) / 64), ks);
-    if (coal) launch_f16(dcn_f16x3_kernel<2, 2, 1, true>, grid, 0, st, k);
+    const dim3 grid1((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 63) / 64), ks);
+    if (ct1 && coal) launch_f16(dcn_f16x3_kernel<2, 2, 1, true, 1>, grid1, 0, st, k);
+    else if (coal) launch_f16(dcn_f16x3_kernel<2, 2, 1, true>, grid, 0, st, k);
     else launch_f16(dcn_f16x3_kernel<2, 2, 1, false>, grid, 0, st, k);
   } else if (a->N_pad <= 128) {  // 128 channels: 4 x 32-channel wave rows, 64 pixels
     const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((a->N_pad + 127) / 128), ks);
