@@ -876,7 +876,8 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const i
   // gone).  The tile shape changes no sum (same K order, same WK): results are bit-identical, so this MAY depend on the
   // batch size; the patch is tiled (8 x 16) whatever the map - tile quantisation costs nothing on an empty chip.
   const long tiles8x16 = (long)((a->H + 7) / 8) * ((a->W + 15) / 16) * B;
-  auto one_round = [&](long wgs) { return wgs <= 256; };
+  static const long round_wgs = [] { const char* e = getenv("CF_CONV3_ONE_ROUND"); return e ? atol(e) : 256L; }();   // (dev A/B of the threshold)
+  auto one_round = [&](long wgs) { return wgs <= round_wgs; };
   if (a->N_pad == 32) {
     if (big && cfg(1) && one_round(tiles8x16)) ok = try_launch<1, 4, 1, 1, 4, true, 2, true, 1>(k, B, st);
     if (ok) {
