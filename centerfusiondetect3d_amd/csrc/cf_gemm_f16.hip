@@ -359,7 +359,13 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
   // 64-channel layers, then always has a full chunk of requests queued behind the one being blended
   // (DEEP only for the two-pixel-group configuration: with WP = 1 the second set costs an occupancy
   //  step or spills and measured slower)
+  // (... and for the half-size tiles, CT = 1: one set keeps them at 114 registers = FOUR workgroups per CU, which beats the
+  //  deeper queue at three: 8 x 64 -> 64 at 112 x 200 106-108 vs 115-116 us, step 7.53 vs 7.63 ms.  CF_DCN_DEEP1: dev A/B)
+#ifdef CF_DCN_DEEP1
   constexpr bool DEEP = WP == 2;
+#else
+  constexpr bool DEEP = WP == 2 && CT == 2;
+#endif
   constexpr int NSET = DEEP ? 2 : 1;
   f32x4 cvs[NSET][NP][4][2];   // 4 corners x 8 channels
   f32x4 cws[NSET][NP];         // corner weights
@@ -888,7 +894,7 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
     if (coal) launch_f16(dcn_f16x3_kernel<4, 1, 1, true>, grid, 0, st, k);
     else launch_f16(dcn_f16x3_kernel<4, 1, 1, false>, grid, 0, st, k);
   } else if (a->N_pad <= 64) {          // 64 channels: 2 x 32-channel wave rows, 2 x 64 pixels
-    // half-size pixel tiles (32 pixels per wave: 156 registers, 39 KB of LDS - three workgroups per CU instead of two): the parts
+    // half-size pixel tiles (32 pixels per wave: 114 registers, 39 KB of LDS - four workgroups per CU instead of two): the parts
     // of this kernel add up instead of overlapping (docs/experiments/r5_dcn_attribution.md), so a third wave per SIMD pays
     // wherever the grid is not many rounds deep - 8 x 64 -> 64 at 112 x 200: 116.5 vs 123.5 us, 8 x 128 -> 64 at 56 x 100: 61.1 vs
     // 72.6 us, 16 x 64 -> 64 at 112 x 200: equal; step 7.75 vs 7.80 ms.  Same K order: bit-identical.  CF_DCN_CT1=0: dev A/B.
