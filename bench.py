@@ -382,9 +382,13 @@ class StepClock:
         self.marks = []          # one stamp per timed step boundary: HIP events on the compute stream (host times on CPU)
 
     def mark(self):
-        """a step boundary on the compute stream: start() before the first timed step, then behind every step's launches.
+        """(no-op with `untimed_marks`: --in-flight > 1 spreads the steps over several caller streams, their boundaries are
+        not on one stream - the distribution then falls back to the mean)
+        a step boundary on the compute stream: start() before the first timed step, then behind every step's launches.
         The distribution of the steps (median, not only a mean) is the differences of consecutive marks -
         device time, so a host that runs a queue ahead does not blur it."""
+        if getattr(self, "untimed_marks", False):
+            return
         if self.cuda:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
@@ -638,6 +642,7 @@ def main():
     clock = StepClock(dev)
 
     flight = [torch.cuda.Stream(dev) for _ in range(args.in_flight)] if args.in_flight > 1 else None
+    clock.untimed_marks = flight is not None
     n_step = [0]
 
     def launches():

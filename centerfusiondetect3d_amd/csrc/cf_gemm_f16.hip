@@ -881,6 +881,7 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   static const int direct_epi = [] { const char* e = getenv("CF_DCN_EPI"); return e ? atoi(e) == 0 : 0; }();
   k.direct_epilogue = direct_epi;
   const bool coal = (a->N & 3) == 0 && !k.direct_epilogue;   // whole-row epilogue through LDS
+  CF_REQUIRE(!a->out_mx || coal, "cf_dcn_v2_f16x3: the mx output is written by the whole-row epilogue (CF_DCN_EPI=0 disables it)");
   // SMALL GRIDS (small batches): 64 output channels on 64-pixel tiles (the 128-channel configuration with two of its
   // four channel-group waves idle in the MFMAs, all four staging) while that launch still fits the chip in one round:
   // 128 -> 64 at 56x100, bs=1: 30.4 vs 43.4 us, bs=2: 31.6 vs 45.0 us; at 350 workgroups the gain is gone.  Same K order,

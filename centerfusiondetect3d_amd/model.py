@@ -456,7 +456,7 @@ class _Plan:
                 # separate pass over the fp32 map only if that kernel is not in use
                 producer = [a for a in self.keep if isinstance(a, _lib.DcnArgs) and a.out == feat.data_ptr()
                             and a.out_scale > 0 and a.N == 64 and a.N_pad == 64]
-                if producer and bool(getattr(model, "pack_mx_fused", True)):
+                if producer and bool(model.pack_mx_fused):
                     producer[-1].out_mx = feat_in.data_ptr()
                     producer[-1].workspace = None          # (the mx output and a K-split reduction exclude each other)
                 else:
@@ -764,7 +764,9 @@ class DLASeg(nn.Module):
         self.heads_mx = True     # ... and the FIRST layer of every fused head as fp16 main term + block-scaled FP6 cross terms
                                  # (v_mfma_scale_f32_16x16x128_f8f6f4): 1.5 MFMA passes per product instead of 3; hidden and
                                  # output layers stay bf16x3 (the float64-anchored gate rejects FP6 cross terms there)
-        self._mx_active = False  # set by _pack: heads_mx and everything it needs (bf16 fused heads on 16x16x32 fragments)
+        self._mx_active = False  # set by _prepare: heads_mx and everything it needs (bf16 fused heads on 16x16x32 fragments)
+        self.pack_mx_fused = True  # with heads_mx: the feature map's DCN writes the heads' operand rows from its epilogue
+                                   # (cf_dcn_args.out_mx); False: a separate cf_pack_feat_mx pass (A/B, byte-identical)
         self.record_spans = False  # dev / tests: keep HIP events around each trunk of _forward_concurrent (trunk_overlap)
         self.trunk_spans = []
         self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
