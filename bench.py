@@ -556,6 +556,9 @@ def main():
                          "sub-batch fills launches that cannot fill the chip alone); the heads - the roofline kernel - "
                          "run for the whole batch on the caller's stream, so their HIP-event durations overlap nothing.  "
                          "1 = everything on one stream")
+    ap.add_argument("--min-sub-batch", type=int, default=None,
+                    help="model.min_sub_batch (frames a trunk stream must keep; default 6): with --streams 4 --min-sub-batch 4 a "
+                         "bs=16 step runs four 4-frame trunks (experiment)")
     ap.add_argument("--exact-fp32", action="store_true",
                     help="every product in exact fp32 (fp32 MFMA kernels with two-level summation; conv_f16 / heads_bf16 "
                          "off) instead of the default split-operand products - the accuracy reference build, 3.5x slower")
@@ -630,6 +633,8 @@ def main():
         model.heads_mx = False
     model = synthetic_weights(model, seed=0, offset_std=args.offset_std).to(dev).eval()
     model.streams = max(1, args.streams)
+    if args.min_sub_batch is not None:
+        model.min_sub_batch = args.min_sub_batch
     model.use_graph = bool(args.use_graph)
     if args.end_to_end:
         if rank == 0:
