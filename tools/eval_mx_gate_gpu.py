@@ -1,0 +1,45 @@
+"""Dev tool (GPU box): the float64-anchored accuracy gate of tests/test_gpu_model.py (RMS error of the HIP path against the
+float64 oracle <= 1.25 x the fp32 oracle's own, worst element <= 2 x + 2e-5) over several weight / input seeds, with the
+heads' first layers on fp16 + FP6 (default) and on bf16x3 (--heads-bf16x3): how much margin the scheme keeps.
+    python tools/eval_mx_gate_gpu.py [n_seeds] [--heads-bf16x3]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import model_ref, frustum_ref
+from tests.golden import cases
+from centerfusiondetect3d_amd import getModel, centerfusion_middle_config
+
+n_seeds = int(next((a for a in sys.argv[1:] if not a.startswith("--")), "4"))
+mx = "--heads-bf16x3" not in sys.argv
+dev = torch.device("cuda:0")
+H, W, B = 448, 800, 1
+worst_ratio, worst_max = 0.0, 0.0
+for seed in ([int(a.split("=")[1]) for a in sys.argv if a.startswith("--seed=")] or range(n_seeds)):
+    sd = cases.tuned_state_dict(radar=True, seed=seed)
+    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=100 + seed, radar=True, n_points=(80, 200))
+    with torch.no_grad():
+        r32 = model_ref.forward(sd, x, pc_dep=pc_dep, calib=calib, radar=True)[0]
+        hm = frustum_ref.pc_frustum_heatmap(r32, pc_dep, calib, 100, 60.0)
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        r64 = model_ref.forward(sd64, x.double(), pc_dep=pc_dep.double(), calib=calib, radar=True, pc_hm_override=hm)[0]
+        m = getModel(centerfusion_middle_config((H, W)))
+        m.heads_mx = mx
+        m.load_state_dict(sd)
+        m = m.to(dev).eval()
+        y = m(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))[0]
+    assert torch.equal(y["pc_hm"].cpu(), r32["pc_hm"]), "frustum map differs from the fp32 oracle's"
+    line = []
+    for k, t in r64.items():
+        if k in ("calib", "pc_hm", "pc_hm_in", "pc_hm_out"):
+            continue
+        g, c = y[k].double().cpu(), r32[k].double()
+        scale, rms = float(t.abs().max()) + 1e-300, float(t.pow(2).mean().sqrt()) + 1e-300
+        r_gpu, r_cpu = float((g - t).pow(2).mean().sqrt()) / rms, float((c - t).pow(2).mean().sqrt()) / rms
+        e_gpu, e_cpu = float((g - t).abs().max()) / scale, float((c - t).abs().max()) / scale
+        ratio = r_gpu / (r_cpu + 1e-300)
+        ok = r_gpu <= 1.25 * r_cpu + 2e-6 and e_gpu <= 2.0 * e_cpu + 2e-5
+        worst_ratio = max(worst_ratio, ratio if r_cpu > 1e-6 else 0.0)
+        worst_max = max(worst_max, e_gpu / (2.0 * e_cpu + 2e-5))
+        line.append(f"{k}:{ratio:.2f}{'' if ok else '(FAIL)'}" + (f"[{r_gpu:.1e}/{r_cpu:.1e}]" if "--abs" in sys.argv else ""))
+    print(f"seed {seed} ({'fp16+FP6 first layers' if mx else 'bf16x3'}): rms hip / rms fp32-oracle  " + "  ".join(line), flush=True)
+print(f"worst RMS ratio {worst_ratio:.3f} (gate 1.25); worst max-norm / allowed {worst_max:.3f} (gate 1)")
