@@ -151,6 +151,49 @@ def test_forward_matches_reference_golden(dev, golden_dir, tag, radar, B, H, W):
             assert torch.equal(out2[0][k], y[k]), f"{k}: forward is not deterministic"
 
 
+@pytest.mark.parametrize("flags", [dict(heads_mx=False), dict(pack_mx_fused=False)], ids=["heads_bf16x3", "separate_pack_pass"])
+def test_forward_matches_reference_golden_on_the_switchable_head_paths(dev, golden_dir, flags):
+    """the A/B switches of the heads' first layer keep working at module level: `heads_mx = False` (bf16x3, the round-4
+    arithmetic - bench.py --heads-bf16x3) against the reference's golden outputs with the same tolerance, and
+    `pack_mx_fused = False` (cf_pack_feat_mx as its own launch instead of the DCN epilogue): same tolerance, and bit-identical to the
+    default wherever the producing DCN does not split K"""
+    from centerfusiondetect3d_amd import getModel, centerfusion_middle_config
+    B, H, W = 2, 128, 160
+    g = np.load(os.path.join(golden_dir, "model_centerfusion_small.npz"))
+    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=1, radar=True)
+    m = getModel(centerfusion_middle_config((H, W)))
+    for k, v in flags.items():
+        setattr(m, k, v)
+    m.load_state_dict(cases.tuned_state_dict(radar=True, seed=0), strict=True)
+    m = m.to(dev).eval()
+    with torch.no_grad():
+        y = m(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))[0]
+        ref = _model(True, dev, (H, W))(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))[0]
+    assert m._mx_active == bool(flags.get("heads_mx", True))
+    for k, v in y.items():
+        if k == "calib":
+            continue
+        _assert_maps_close(v, g[f"out_{k}"], k)
+    assert np.array_equal((y["pc_hm"] != 0).cpu().numpy(), g["out_pc_hm"] != 0)
+    del ref
+    if "pack_mx_fused" in flags:
+        # (at 32 x 40 the feature map's DCN splits K unless it writes the rows itself, so the two forms differ in rounding
+        #  there; on a map above the K-split size they are the same arithmetic: bit-identical)
+        H2, W2 = 192, 256
+        x2, pc2, cal2 = cases.model_inputs(1, H2, W2, seed=2, radar=True)
+        outs = []
+        for fused in (True, False):
+            m2 = getModel(centerfusion_middle_config((H2, W2)))
+            m2.pack_mx_fused = fused
+            m2.load_state_dict(cases.tuned_state_dict(radar=True, seed=0), strict=True)
+            m2 = m2.to(dev).eval()
+            with torch.no_grad():
+                outs.append(m2(x2.to(dev), pc_dep=pc2.to(dev), calib=cal2.to(dev))[0])
+        for k in outs[0]:
+            if k != "calib":
+                assert torch.equal(outs[0][k], outs[1][k]), k
+
+
 def test_forward_and_decode_fullres_vs_reference_samples(dev, golden_dir):
     from centerfusiondetect3d_amd import fusionDecode
     g = np.load(os.path.join(golden_dir, "model_centerfusion_fullres.npz"))
