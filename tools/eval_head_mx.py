@@ -1,5 +1,9 @@
+"""Dev tool (CPU): gate (a) of the heads' FP6 scheme - the oracle's head chain under each candidate arithmetic (bf16x3; fp16 main
+term + block-scaled FP6 cross terms on the first layer / on every layer / with refined weights) against the float64-anchored
+bounds of tests/test_gpu_model.py.  Raw output of the round: docs/experiments/r5_heads_mx_numerics.txt.
+    python tools/eval_head_mx.py /tmp/e2e_2_448_800.pt [variant names ...]"""
 import sys, time, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch.nn.functional as F
 from oracle import model_ref, mx_emul
 from tests.golden import cases
@@ -16,21 +20,29 @@ def mm_bf16x3(w, x):
     wh, wl = sp(w); xh, xl = sp(x)
     return ((wh @ xh).float() + ((wh @ xl).float() + (wl @ xh).float()))
 
-def mm_mx(w, x, refine_w=False, own_lo=False):
+def mm_mx(w, x, refine_w=False, own_lo=True):
+    """(N, K) x (K, P) with oracle/mx_emul.py's quantiser (numpy): fp16 main term + FP6 cross terms; own_lo: the lo block takes
+    its exponent from its own maximum (what the kernels do) instead of the hi block's exponent - 11"""
+    import numpy as np
     s = mx_emul.weight_scale_exp(w)
-    wh, wl = mx_emul.split_f16(w.double().mul(2.0 ** s).float())
-    xh, xl = mx_emul.split_f16(x.float() * 16.0)
-    q = mx_emul.q6_blocks
-    wh6, wl6 = q(wh, 1), q(wl, 1)
+    wh, wl = mx_emul.split_f16((w.double() * 2.0 ** s).float().numpy())
+    xh, xl = mx_emul.split_f16((x.float() * 16.0).numpy().T)             # (P, K): blocks of 32 along K
+    q = lambda v: mx_emul.quant_blocks(v)[2]
+    wh6, wl6 = q(wh), q(wl)
     if refine_w:
-        wh6 = wh6 + q(wh - wh6, 1); wl6 = wl6 + q(wl - wl6, 1)
-    xb = xh.movedim(0, -1).reshape(x.shape[1], -1, 32).double()
-    e_hi = mx_emul.block_exponent(xb.abs().amax(-1, keepdim=True))
-    xh6 = q(xh, 0, exponent=e_hi)
-    xl6 = q(xl, 0, exponent=None if own_lo else e_hi - 11)
-    main = (wh.double() @ xh.double()).float()
-    cross = (wh6.double() @ xl6.double() + wl6.double() @ xh6.double()).float()
-    return (main + cross) * (2.0 ** -(s + 4))
+        wh6 = wh6 + q(wh - wh6)
+        wl6 = wl6 + q(wl - wl6)
+    xh6 = q(xh)
+    if own_lo:
+        xl6 = q(xl)
+    else:
+        codes, e, _ = mx_emul.quant_blocks(xh)
+        b_ = xl.astype(np.float64).reshape(xl.shape[0], -1, 32)
+        sc = np.ldexp(1.0, e - 11)[..., None]
+        xl6 = (mx_emul.e2m3_values(mx_emul.e2m3_codes(b_ / sc)) * sc).reshape(xl.shape)
+    main = wh.astype(np.float64) @ xh.astype(np.float64).T
+    cross = wh6 @ xl6.T + wl6 @ xh6.T
+    return torch.from_numpy(((main.astype(np.float32) + cross.astype(np.float32)) * np.float32(2.0 ** -(s + 4))))
 
 def conv(x, weight, bias, pad, mm):
     B, C, H, W = x.shape
@@ -50,7 +62,7 @@ def head(p, x, n_hidden, mms):
         idx += 2
     return conv(x, sd[f"{p}.{idx}.weight"], sd[f"{p}.{idx}.bias"], 0, mms[2])
 
-mx = lambda w, x: mm_mx(w, x)
+mx = lambda w, x: mm_mx(w, x, own_lo=False)
 mxo = lambda w, x: mm_mx(w, x, own_lo=True)
 mxr = lambda w, x: mm_mx(w, x, refine_w=True, own_lo=True)
 variants = {
