@@ -6,7 +6,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcfhip.so")
 
-ABI_VERSION = 4      # CF_ABI_VERSION of include/cf_hip.h this binding was written against
+ABI_VERSION = 5      # CF_ABI_VERSION of include/cf_hip.h this binding was written against
 CF_MAX_SRC = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, ACT_RAW_AND_SIGDEPTH = 0, 1, 2, 3
 LAYOUT_NHWC, LAYOUT_NCHW, LAYOUT_NHWC_SPLIT_BF16 = 0, 1, 2
@@ -83,6 +83,7 @@ SYMBOLS = {
     "cf_conv2d_f16x3": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_conv3x3_f16x3": (_i, [C.POINTER(ConvArgs), _f]),
     "cf_conv3x3_root_f16x3": (_i, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.POINTER(C.c_int32), _f]),
+    "cf_conv3x3_proj_f16x3": (_i, [C.POINTER(ConvArgs), C.POINTER(C.c_int32), _f]),
     "cf_stem_fused": (_i, [C.POINTER(StemArgs), _f]),
     "cf_split_bf16": (_i, [_f, _f, C.c_long, _i, _i, _i, _f]),
     "cf_head_tail": (_i, [C.POINTER(HeadTailArgs), _f]),

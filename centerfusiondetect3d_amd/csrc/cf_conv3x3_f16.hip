@@ -68,6 +68,9 @@ struct Conv3F {
   int root_xsrc_c[2], root_xsrc_ch[2];   // floats per pixel, channels (multiples of 64)
   int root_nks;                          // k-steps of the whole Root: (2 N + children's channels) / 16
   float out_scale;
+  // PROJ only: a 1x1 convolution of a second tensor (same map as the output) summed into the same accumulators
+  const float* proj_x;
+  int proj_c, proj_ch, proj_nks, proj_ks0;   // floats per pixel, channels (multiple of 32), k-steps, first k-step in the stream
 };
 
 // T2: the R pixels are an (R/16) x 16 tile of ONE image instead of a flat run: the patch is the tile
@@ -84,9 +87,17 @@ struct Conv3F {
 // waves of a pixel group read each other's pieces) 8 WC k-steps of MFMAs follow in the slot kernel's order, each wave
 // producing its own 64 output channels.  Only the Root's output goes to HBM: x2 is never written (unless p.out is
 // given), x1 is read once for both uses, one launch less.
-template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2, int CT = 2, bool S2 = false, bool ROOT = false>
+// PROJ (BasicBlock conv2 of the sub-tree that opens a DLA level: its residual is the Tree's `project` - 1x1 convolution
+// + BN - of the 2x2-max-pooled level input, dla.py:96-107, 56-62): the projection's k-steps run behind the 3x3 part, into
+// the same accumulators, so the residual never exists as a tensor and its launch is gone.  B tiles of 32 pixels x 64 channels:
+// the WC x WK waves of a pixel group each fetch one 64-channel piece of the pooled rows from HBM (whole rows), split it
+// to fp16 hi / lo into their LDS region, and after the group's barrier every wave multiplies the round's pieces in K
+// order (WK > 1: piece i goes to K-split wave i % WK).  The regions are the patch buffers' memory (dead by then).
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2, int CT = 2, bool S2 = false, bool ROOT = false,
+          bool PROJ = false>
 __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(Conv3F p) {
   static_assert(!ROOT || (WK == 1 && RT == 2 && !S2 && 64 * WC * WP * WK == 256), "Root fusion: 64-channel waves, 4 waves, every channel of a pixel in the workgroup");
+  static_assert(!PROJ || (!S2 && !ROOT), "projection k-steps: stride 1, no fused Root");
   constexpr int NT = 64 * WC * WP * WK;     // 4 waves, or 8 (WP doubled: two pixel groups share each weight fragment through L1)
   static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
   static_assert(!S2 || (T2 && WK == 1), "stride 2: tiled form, no K split");
@@ -325,6 +336,102 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
     __syncthreads();
 #endif
     PROF_MARK(2)
+  }
+
+  // ---- PROJ: the projection's k-steps, behind the 3x3 part (the patch is dead: its memory holds the B tiles)
+  if constexpr (PROJ) {
+    constexpr int BROW = 144;                // B tile: 64 f16 + 16 B per pixel row and plane
+    constexpr int BPLANE = 32 * BROW;
+    constexpr int REG = 2 * BPLANE;          // hi and lo plane of one piece: 9216 B
+    constexpr int NG = WC * WK;              // waves of a pixel group
+    int tid_p = threadIdx.x;                 // (every lane-derived index re-derived here, as in the epilogues: nothing of
+    asm volatile("" : "+v"(tid_p));          //  this phase lives in registers across the main loop)
+    const int lane = tid_p & 63, li = lane & 31, h = lane >> 5;
+    const int gw = wc * WK + wk;
+    unsigned char* myreg = smem + (gw * WP + wp) * REG;
+    const int chunk = lane & 15, psub = lane >> 4;       // 16 lanes = one pixel's 64 channels, 4 pixels per instruction
+    const int n_pieces = (p.proj_nks + 3) >> 2;           // (the last piece may hold 32 channels: level 2)
+    auto group_sync = [&]() {
+      if (NG > 1) __syncthreads();
+      else cf_wave_lds_sync();
+    };
+    f16x8 pwh[4][RT], pwl[4][RT];
+    auto load_pw = [&](int piece) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int ks = p.proj_ks0 + min(piece * 4 + kk, p.proj_nks - 1);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const unsigned char* base = p.weight + ((long)(w_ok ? rt0 + rt : 0) * p.n_ks + ks) * 2048;
+          pwh[kk][rt] = *reinterpret_cast<const f16x8*>(base + (unsigned)lane * 16u);
+          pwl[kk][rt] = *reinterpret_cast<const f16x8*>(base + 1024 + (unsigned)lane * 16u);
+        }
+      }
+    };
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      for (int e0 = 0; e0 < n_pieces; e0 += NG) {
+        group_sync();                        // the previous round's fragments have been read: the regions are free
+        const int e = e0 + gw;
+        if (e < n_pieces) {
+          const int cw = min(64, p.proj_ch - e * 64);
+          // (two batches of four rows: eight rows in flight beside the accumulators and the weight fragments spill)
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb) {
+            f32x4 xv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int pl = wp * (32 * CT) + ct * 32 + (hb * 4 + j) * 4 + psub;
+              int m = m0 + pl;
+              bool ok = chunk * 4 < cw;
+              if (T2) {
+                const int y = ty0 + (pl >> 4), x = tx0 + (pl & 15);
+                ok = ok && y < p.H && x < p.W;
+                m = m0 + y * p.W + x;
+              } else {
+                ok = ok && m < p.M;
+              }
+              xv[j] = ok ? *reinterpret_cast<const f32x4*>(p.proj_x + (size_t)m * p.proj_c + e * 64 + chunk * 4)
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x4 xs = xv[j] * ASCALE;
+              uint2 hi2, lo2;
+              split2(xs[0], xs[1], hi2.x, lo2.x);
+              split2(xs[2], xs[3], hi2.y, lo2.y);
+              unsigned char* o = myreg + ((hb * 4 + j) * 4 + psub) * BROW + chunk * 8;
+              *reinterpret_cast<uint2*>(o) = hi2;
+              *reinterpret_cast<uint2*>(o + BPLANE) = lo2;
+            }
+            asm volatile("" ::: "memory");   // (the next batch / the weight fragments are requested behind these stores)
+          }
+        }
+        const int np = min(NG, n_pieces - e0);
+        int i = wk;
+        if (i < np) load_pw(e0 + i);         // (requested in front of the barrier)
+        group_sync();
+        for (; i < np; i += WK) {
+          const unsigned char* reg = smem + (i * WP + wp) * REG + li * BROW + h * 16;
+          const int nk = min(4, p.proj_nks - (e0 + i) * 4);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            if (kk < nk) {
+              const f16x8 bh = *reinterpret_cast<const f16x8*>(reg + kk * 32);
+              const f16x8 bl = *reinterpret_cast<const f16x8*>(reg + kk * 32 + BPLANE);
+#pragma unroll
+              for (int rt = 0; rt < RT; ++rt) {
+                accs[rt][ct] = CF_MFMA_F16(pwl[kk][rt], bh, accs[rt][ct]);
+                accm[rt][ct] = CF_MFMA_F16(pwh[kk][rt], bh, accm[rt][ct]);
+                accs[rt][ct] = CF_MFMA_F16(pwh[kk][rt], bl, accs[rt][ct]);
+              }
+            }
+          }
+          if (i + WK < np) load_pw(e0 + i + WK);
+        }
+      }
+    }
+    __syncthreads();                         // every region has been read: the memory becomes the K-split / epilogue tiles
   }
 
   // ---- K-split waves: partial sums -> LDS, added by wave wk == 0 in fixed order
@@ -670,7 +777,8 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
 #endif
 }
 
-template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2 = false, int CT = 2, bool S2 = false, bool ROOT = false>
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2 = false, int CT = 2, bool S2 = false, bool ROOT = false,
+          bool PROJ = false>
 bool try_launch(Conv3F k, int batch, hipStream_t st) {
   constexpr int R = 32 * CT * WP, ROWB = 64 * WK + 16;
   long blocks;
@@ -697,12 +805,23 @@ bool try_launch(Conv3F k, int batch, hipStream_t st) {
     if (dyn < root_lds) dyn = root_lds;
     if (dyn > 80 * 1024) return false;
   }
-  auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB, T2, CT, S2, ROOT>;
+  if (PROJ) {
+    constexpr size_t proj_lds = (size_t)(NT / 64) * 9216;   // one B-tile region per wave
+    if (dyn < proj_lds) dyn = proj_lds;
+  }
+  auto kernel = conv3x3_f16x3_kernel<WC, WP, WK, RT, NU, DB, MINB, T2, CT, S2, ROOT, PROJ>;
   static CfLdsLimit lds_limit;                // (one per template instantiation)
   lds_limit.ensure(kernel, dyn, 65536);
   const dim3 grid((unsigned)blocks, (unsigned)((k.n_rt + WC * RT - 1) / (WC * RT)));
   hipLaunchKernelGGL(kernel, grid, dim3(NT), dyn, st, k);
   return true;
+}
+
+// the default tilings of the 64+ channel layers, with or without the projection k-steps in front
+template <int WC, int WP, int WK, int RT, int NU, bool DB, int MINB, bool T2 = false, int CT = 2>
+bool launch_p(const Conv3F& k, int batch, hipStream_t st) {
+  return k.proj_x ? try_launch<WC, WP, WK, RT, NU, DB, MINB, T2, CT, false, false, true>(k, batch, st)
+                  : try_launch<WC, WP, WK, RT, NU, DB, MINB, T2, CT>(k, batch, st);
 }
 
 // 16 x 16 tiles cover the map with at most ~6 % of the tile area outside it
@@ -715,9 +834,12 @@ bool tiles_fit(int H, int W) {
 
 // A geometry that fits no patch configuration is forwarded to cf_conv2d_f16x3 (same packed weights).
 // root != nullptr (cf_conv3x3_root_f16x3, already validated): try the fused conv2 + Root launch first; *fused says whether it ran.
-static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const int32_t* root_ch, bool* fused, void* stream) {
+// proj_ch != nullptr (cf_conv3x3_proj_f16x3, already validated): src[1] is the 1x1 projection's source, proj_ch = the real
+// channels of (the 3x3 source, the projection's source).
+static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const int32_t* root_ch, bool* fused, void* stream,
+                        const int32_t* proj_ch = nullptr) {
   CF_REQUIRE(a != nullptr, "cf_conv3x3_f16x3: null args");
-  CF_REQUIRE(a->n_src == 1 && a->src[0] && a->src_c[0] > 0 && a->src_c[0] % 4 == 0, "cf_conv3x3_f16x3: one fp32 NHWC source");
+  CF_REQUIRE(a->n_src == (proj_ch ? 2 : 1) && a->src[0] && a->src_c[0] > 0 && a->src_c[0] % 4 == 0, "cf_conv3x3_f16x3: one fp32 NHWC source");
   const bool s2 = a->stride == 2;
   CF_REQUIRE((a->stride == 1 && a->Ho == a->H && a->Wo == a->W) ||
              (s2 && a->Ho == (a->H - 1) / 2 + 1 && a->Wo == (a->W - 1) / 2 + 1), "cf_conv3x3_f16x3: 3x3, pad 1, stride 1 or 2");
@@ -731,8 +853,12 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const i
   CF_REQUIRE(a->act == CF_ACT_NONE || a->act == CF_ACT_RELU, "cf_conv3x3_f16x3: act=%d unsupported", a->act);
   CF_REQUIRE(a->out_scale > 0.0f, "cf_conv3x3_f16x3: out_scale must be the 2^-(s+4) the weights were packed with");
   CF_REQUIRE(!a->residual || a->res_stride % 4 == 0, "cf_conv3x3_f16x3: residual stride must be a multiple of 4");
-  // K_pad = 16 * 9 * slices, rounded up to a multiple of 32
-  const int slices = a->K_pad / 144;
+  // K_pad = 16 * 9 * slices, rounded up to a multiple of 32 (+ the projection's channels behind it)
+  const int slices = proj_ch ? proj_ch[0] / 16 : a->K_pad / 144;
+  if (proj_ch)
+    CF_REQUIRE(slices >= 2 && slices % 2 == 0 && a->K_pad == slices * 144 + proj_ch[1],
+               "cf_conv3x3_proj_f16x3: K_pad=%d is not a slice-major 3x3 packing of %d channels + %d projected ones", a->K_pad, proj_ch[0], proj_ch[1]);
+  else
   CF_REQUIRE(slices >= 1 && (a->K_pad == slices * 144 || a->K_pad == slices * 144 + 16),
              "cf_conv3x3_f16x3: K_pad=%d is not a slice-major 3x3 packing", a->K_pad);
   CF_REQUIRE(slices * 16 <= a->src_c[0], "cf_conv3x3_f16x3: %d input channels exceed the source width %d", slices * 16, a->src_c[0]);
@@ -748,6 +874,13 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const i
   k.n_rt = a->N_pad / 32; k.n_ks = a->K_pad / 16;
   k.res_stride = a->res_stride; k.out_stride = a->out_stride; k.act = a->act;
   k.out_scale = a->out_scale;
+  if (proj_ch) {
+    k.proj_x = a->src[1];
+    k.proj_c = a->src_c[1];
+    k.proj_ch = proj_ch[1];
+    k.proj_nks = proj_ch[1] / 16;
+    k.proj_ks0 = slices * 9;                 // the projection's k-steps sit behind the 3x3 part
+  }
   hipStream_t st = (hipStream_t)stream;
   bool ok = false;
   const int B = a->B;
@@ -814,7 +947,7 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const i
   }
   // dev override (tools/bench_conv_cfg.py): CF_CONV3_CFG="WC,WP,WK[,T2]" forces one of the instantiated tilings
   static const int only_n = [] { const char* e = getenv("CF_CONV3_ONLY_N"); return e ? atoi(e) : 0; }();   // (dev: override one width only)
-  if (const char* force = (only_n == 0 || only_n == a->N_pad) ? getenv("CF_CONV3_CFG") : nullptr) {
+  if (const char* force = (!proj_ch && (only_n == 0 || only_n == a->N_pad)) ? getenv("CF_CONV3_CFG") : nullptr) {
     int wc = 0, wp = 0, wk = 0, t2f = 0, ct = 2, rt = 2;
     if (sscanf(force, "%d,%d,%d,%d,%d,%d", &wc, &wp, &wk, &t2f, &ct, &rt) >= 3 && cfg(wk)) {
       const int key = wc * 100 + wp * 10 + wk;
@@ -890,16 +1023,16 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const i
       if (!ok && cfg(1)) ok = try_launch<1, 4, 1, 1, 12, true, 1>(k, B, st);
     }
   } else if (a->N_pad == 64) {
-    if (cfg(1)) ok = (one_round(tiles8x16) && try_launch<1, 4, 1, 2, 4, true, 2, true, 1>(k, B, st)) ||
-                     (t2 && try_launch<1, 4, 1, 2, 6, true, 2, true>(k, B, st)) || try_launch<1, 4, 1, 2, 6, true, 2>(k, B, st);
+    if (cfg(1)) ok = (one_round(tiles8x16) && launch_p<1, 4, 1, 2, 4, true, 2, true, 1>(k, B, st)) ||
+                     (t2 && launch_p<1, 4, 1, 2, 6, true, 2, true>(k, B, st)) || launch_p<1, 4, 1, 2, 6, true, 2>(k, B, st);
   } else if (a->N_pad == 128) {
     // (the one-wave-per-SIMD form - CT = 4, 64-channel x 128-pixel wave tiles, accumulators in AGPRs, CF_CONV3_CFG
     //  "2,2,1,0,4" - is bit-identical and measured 97-123 us against 76-92 us here: DESIGN.md section 9)
     // wide maps (3x896x1600: level 3 is 112 x 200): 8 x 16 tiles with a frame - the flat run's patch (R + 2W + 2 rows)
     // no longer fits, and falling back to the slot kernel re-gathers every input 9 times
-    if (cfg(1)) ok = (one_round(2 * tiles8x16) && try_launch<1, 4, 1, 2, 4, true, 2, true, 1>(k, B, st)) ||   // (64 channels per workgroup)
-                     (t2 && try_launch<2, 2, 1, 2, 4, true, 2, true>(k, B, st)) || try_launch<2, 2, 1, 2, 6, true, 2>(k, B, st) ||
-                     try_launch<2, 2, 1, 2, 4, true, 2, true>(k, B, st);   // (8 waves x 256 pixels measured 4 % slower here)
+    if (cfg(1)) ok = (one_round(2 * tiles8x16) && launch_p<1, 4, 1, 2, 4, true, 2, true, 1>(k, B, st)) ||   // (64 channels per workgroup)
+                     (t2 && launch_p<2, 2, 1, 2, 4, true, 2, true>(k, B, st)) || launch_p<2, 2, 1, 2, 6, true, 2>(k, B, st) ||
+                     launch_p<2, 2, 1, 2, 4, true, 2, true>(k, B, st);   // (8 waves x 256 pixels measured 4 % slower here)
   } else {
     // 256+ channels: every 64-pixel tile streams the whole weight matrix from L2, which bounds these
     // layers - with enough tiles to go round, 8 waves (two pixel groups per channel group, 128 pixels)
@@ -909,18 +1042,34 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const i
     // doubles the workgroup count and halves every wave's round chain (per-image rule, see above)
     const long runs32 = (M + 31) / 32;
     if ((long)a->H * a->W <= 512 && cfg(2))
-      ok = (one_round(runs32 * ((a->N_pad + 127) / 128)) && try_launch<2, 1, 2, 2, 4, true, 2, false, 1>(k, B, st)) ||
-           try_launch<2, 1, 2, 2, 4, true, 2>(k, B, st);
-    if (!ok && cfg(1) && one_round(runs32 * ((a->N_pad + 255) / 256))) ok = try_launch<4, 1, 1, 2, 4, true, 2, false, 1>(k, B, st);
+      ok = (one_round(runs32 * ((a->N_pad + 127) / 128)) && launch_p<2, 1, 2, 2, 4, true, 2, false, 1>(k, B, st)) ||
+           launch_p<2, 1, 2, 2, 4, true, 2>(k, B, st);
+    if (!ok && cfg(1) && one_round(runs32 * ((a->N_pad + 255) / 256))) ok = launch_p<4, 1, 1, 2, 4, true, 2, false, 1>(k, B, st);
     // (the tiled forms behind the flat ones: maps wider than ~60 / ~95 pixels, e.g. level 4 of a 3x896x1600 input)
-    if (!ok && cfg(1)) ok = (tiles128 >= 160 && (try_launch<4, 2, 1, 2, 2, true, 1>(k, B, st) || try_launch<4, 2, 1, 2, 2, true, 1, true>(k, B, st))) ||
-                            try_launch<4, 1, 1, 2, 4, true, 2>(k, B, st) || try_launch<4, 1, 1, 2, 2, true, 2, true>(k, B, st);
+    if (!ok && cfg(1)) ok = (tiles128 >= 160 && (launch_p<4, 2, 1, 2, 2, true, 1>(k, B, st) || launch_p<4, 2, 1, 2, 2, true, 1, true>(k, B, st))) ||
+                            launch_p<4, 1, 1, 2, 4, true, 2>(k, B, st) || launch_p<4, 1, 1, 2, 2, true, 2, true>(k, B, st);
   }
   if (!ok) return cf_conv2d_f16x3(a, stream);
   return cf_check_launch("cf_conv3x3_f16x3");
 }
 
 extern "C" int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream) { return conv3x3_impl(a, nullptr, nullptr, nullptr, stream); }
+
+// BasicBlock conv2 whose residual is the Tree's `project` (1x1 convolution + BN of the pooled level input, dla.py:96-107):
+// src[1] = the pooled tensor, its k-steps packed behind the 3x3 part (packing.pack_conv_f16(proj=...)); one launch, the
+// residual tensor never exists.  Geometries no patch tiling fits run the slot kernel on the same table.
+extern "C" int cf_conv3x3_proj_f16x3(const cf_conv_args* a, const int32_t* src_channels, void* stream) {
+  CF_REQUIRE(a != nullptr && src_channels != nullptr, "cf_conv3x3_proj_f16x3: null args");
+  CF_REQUIRE(a->n_src == 2 && a->src[0] && a->src[1], "cf_conv3x3_proj_f16x3: two sources (3x3 input, projected tensor)");
+  CF_REQUIRE(a->stride == 1 && a->N_pad >= 64, "cf_conv3x3_proj_f16x3: stride 1, 64+ output channels");
+  CF_REQUIRE(src_channels[0] >= 32 && src_channels[0] % 32 == 0 && src_channels[0] <= a->src_c[0] && a->src_c[0] % 8 == 0,
+             "cf_conv3x3_proj_f16x3: %d channels of the 3x3 source (width %d)", src_channels[0], a->src_c[0]);
+  CF_REQUIRE(src_channels[1] >= 32 && src_channels[1] % 32 == 0 && src_channels[1] <= a->src_c[1] && a->src_c[1] % 8 == 0,
+             "cf_conv3x3_proj_f16x3: %d channels of the projected source (width %d)", src_channels[1], a->src_c[1]);
+  CF_REQUIRE((long)a->B * a->H * a->W * a->src_c[1] < (1L << 31), "cf_conv3x3_proj_f16x3: tensor too large");
+  CF_REQUIRE(a->slots != nullptr, "cf_conv3x3_proj_f16x3: the slot table is needed (fallback)");
+  return conv3x3_impl(a, nullptr, nullptr, nullptr, stream, src_channels);
+}
 
 // BasicBlock conv2 (+ residual + ReLU) and the Tree's Root over (conv2's output, conv2's residual) as ONE launch where
 // a workgroup holds every channel of its pixels (64-channel layers); everything else runs the two launches.  Same

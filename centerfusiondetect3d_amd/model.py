@@ -313,17 +313,36 @@ class _Plan:
             pooled[x.data_ptr()] = o
             return o
 
-        def block(p, x, residual):
+        def block(p, x, residual, pooled=None):
             _, h, w, _ = x.shape
             t, _ = conv(p + ".conv1", [x], h, w)
             _, ho, wo, _ = t.shape
+            if pooled is not None:
+                # conv2 + the Tree's project of the pooled input in one step (weights packed together: _prepare.tree1)
+                pc = pk[p + ".conv2"]
+                o = buf(B, ho, wo, pc.n)
+                a = ops.conv_args(pc, [t, pooled], [t.shape[-1], pooled.shape[-1]], B, ho, wo, o, pc.n, ACT_RELU, None, 0,
+                                  LAYOUT_NHWC, None, 0, False)
+                ch = (C.c_int32 * 2)(*[int(c) for c in pc.real_cin])
+                self.keep += [a, ch]
+                name = p + ".conv2+project"
+                self.step_index[name] = len(self.steps)
+                self.step_flops[name] = 2.0 * B * ho * wo * pc.n * (9 * pc.real_cin[0] + pc.real_cin[1])
+                if model.conv_patch:
+                    self.add_step((self.lib.cf_conv3x3_proj_f16x3, C.byref(a), ch))
+                else:
+                    self.add_step((self.lib.cf_conv2d_f16x3, C.byref(a)))
+                return o
             o, _ = conv(p + ".conv2", [t], ho, wo, residual=residual if residual is not None else x)
             return o
 
         def tree(p, levels, x, stride, level_root, children=None):
             children = [] if children is None else children
             bottom = pool(x) if stride > 1 else x
-            if (p + ".project") in pk:
+            proj_fused = levels == 1 and getattr(pk[p + ".tree1.conv2"], "proj_k", 0) > 0
+            if proj_fused:
+                residual = None
+            elif (p + ".project") in pk:
                 _, h, w, _ = bottom.shape
                 residual, _ = conv(p + ".project", [bottom], h, w, act=ACT_NONE)
             else:
@@ -331,7 +350,7 @@ class _Plan:
             if level_root:
                 children.append(bottom)
             if levels == 1:
-                x1 = block(p + ".tree1", x, residual)
+                x1 = block(p + ".tree1", x, residual, pooled=bottom if proj_fused else None)
                 pc2, pcr = pk[p + ".tree2.conv2"], pk[p + ".root"]
                 if (model.root_fuse and model.conv_patch and pc2.out_scale > 0 and pcr.out_scale > 0
                         and getattr(pc2, "patch", False) and pc2.stride == 1):
@@ -757,6 +776,8 @@ class DLASeg(nn.Module):
         self.stem_fused = True   # with conv_f16: base_layer + level0 + level1 in one launch (cf_stem.hip)
         self.conv_patch = True   # 3x3 stride-1 f16x3 convs: LDS patch reuse (cf_conv3x3_f16.hip)
         self.root_fuse = True    # one-level Trees without children: tree2.conv2 + Root as one step (cf_conv3x3_root_f16x3)
+        self.proj_fuse = True    # the sub-tree that opens a level: `project` of the pooled input as k-steps of tree1.conv2
+                                 # (cf_conv3x3_proj_f16x3) instead of a launch + a residual tensor; set before the first forward
         self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)
         self.heads_fused = True  # with heads_bf16: one launch per head group, hidden maps stay in LDS
         self.heads_mfma16 = True # fused heads: first layer + register-fed output layer on v_mfma_f32_16x16x32_bf16 (the
@@ -853,11 +874,18 @@ class DLASeg(nn.Module):
         def tree1(p, ci, co, root_srcs):
             conv_bn(p + ".tree1.conv1", p + ".tree1.conv1.weight", p + ".tree1.bn1", [Source(ci, ci)],
                     stride=2 if ci != co else 1)
-            conv_bn(p + ".tree1.conv2", p + ".tree1.conv2.weight", p + ".tree1.bn2", [Source(co, co)])
+            if f16 and self.proj_fuse and (p + ".project.0.weight") in sd and co >= 64 and ci % 32 == 0:
+                # the Tree's project (dla.py:98-103) rides in tree1.conv2's accumulators: no ".project" entry, no launch
+                w2, b2 = packing.fold_bn(sd[p + ".tree1.conv2.weight"], None, bn(p + ".tree1.bn2"))
+                wp, bp = packing.fold_bn(sd[p + ".project.0.weight"], None, bn(p + ".project.1"))
+                pk[p + ".tree1.conv2"] = packing.pack_conv_f16(w2, b2, [Source(co, co)],
+                                                               proj=(wp, bp, Source(ci, ci))).to(device)
+            else:
+                conv_bn(p + ".tree1.conv2", p + ".tree1.conv2.weight", p + ".tree1.bn2", [Source(co, co)])
             conv_bn(p + ".tree2.conv1", p + ".tree2.conv1.weight", p + ".tree2.bn1", [Source(co, co)])
             conv_bn(p + ".tree2.conv2", p + ".tree2.conv2.weight", p + ".tree2.bn2", [Source(co, co)])
             conv_bn(p + ".root", p + ".root.conv.weight", p + ".root.bn", [Source(c, c) for c in root_srcs])
-            if (p + ".project.0.weight") in sd:
+            if (p + ".project.0.weight") in sd and not pk[p + ".tree1.conv2"].proj_k:
                 conv_bn(p + ".project", p + ".project.0.weight", p + ".project.1", [Source(ci, ci)])
 
         tree1("base.level2", 32, 64, [64, 64])

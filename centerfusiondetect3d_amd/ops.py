@@ -67,6 +67,21 @@ def conv2d_f16x3(pc: PackedConv, srcs, B, H, W, act=ACT_NONE, residual=None, out
     return out
 
 
+def conv3x3_proj_f16x3(pc: PackedConv, t, pooled, act=ACT_RELU, out=None):
+    """BasicBlock conv2 + the Tree's `project` of the pooled level input in ONE launch (cf_conv3x3_proj_f16x3; pc from
+    packing.pack_conv_f16(proj=...)): out = act(conv3x3(t) + project(pooled) + biases)."""
+    _need_cuda(t, pooled)
+    assert pc.proj_k > 0, "weights packed without a projection"
+    B, H, W, _ = t.shape
+    if out is None:
+        out = torch.empty((B, H, W, pc.n), device=t.device, dtype=torch.float32)
+    a = conv_args(pc, [t, pooled], [t.shape[-1], pooled.shape[-1]], B, H, W, out, out.shape[-1], act, None, 0,
+                  LAYOUT_NHWC, None, 0, False)
+    ch = (C.c_int32 * 2)(*[int(c) for c in pc.real_cin])
+    _lib.check(_lib.load().cf_conv3x3_proj_f16x3(C.byref(a), ch, _lib.stream_ptr()), "cf_conv3x3_proj_f16x3")
+    return out
+
+
 def conv3x3_root_f16x3(pc2: PackedConv, pc_root: PackedConv, t, x1, children=(), act_root=ACT_RELU, x2_out=None):
     """One-level Tree tail: x2 = ReLU(conv3x3(t) + x1), out = act(Root([x2, x1, *children])) as ONE launch where the shape
     allows (cf_conv3x3_root_f16x3), the two launches otherwise - same bits.  -> (out, x2 buffer: written only on the fallback)."""

@@ -51,6 +51,7 @@ class PackedConv:
     real_cin: tuple = ()      # real input channels per source (for FLOP accounting)
     out_scale: float = 0.0    # cf_conv2d_f16x3: 2^-(s+4)
     patch: bool = False       # slice-major 3x3 packing: cf_conv3x3_f16x3 may run it
+    proj_k: int = 0           # channels of the 1x1 projection packed behind a slice-major 3x3 (cf_conv3x3_proj_f16x3)
 
     def to(self, device):
         self.weight = self.weight.to(device).contiguous()
@@ -144,7 +145,7 @@ def pack_conv_bf16(weight, bias, sources: Sequence[Source], stride=1, pad=None, 
                       tuple(s.channels for s in sources))
 
 
-def pack_conv_f16(weight, bias, sources: Sequence[Source], stride=1, pad=None, dilation=1) -> PackedConv:
+def pack_conv_f16(weight, bias, sources: Sequence[Source], stride=1, pad=None, dilation=1, proj=None) -> PackedConv:
     """Packing for cf_conv2d_f16x3: fp32 NHWC sources, 8-channel slots (4 per 32-deep chunk), weights
     scaled by 2^s (max|w| -> [2^13, 2^14)), split into fp16 hi/lo and laid out in MFMA A-operand
     fragment order.  PackedConv.out_scale = 2^-(s+4) undoes the weight and activation scales.
@@ -152,7 +153,13 @@ def pack_conv_f16(weight, bias, sources: Sequence[Source], stride=1, pad=None, d
     A 3x3 / pad 1 convolution (stride 1 or 2) of ONE source with C % 16 == 0 is packed SLICE-MAJOR
     (k = (16-channel slice, tap, channel)): that is the order cf_conv3x3_f16x3 (LDS patch reuse)
     consumes, and since the slot table spells the same order out the generic kernel runs the very same
-    weights (PackedConv.patch marks them)."""
+    weights (PackedConv.patch marks them).
+
+    proj = (weight (Cout, Cp, 1, 1), bias (Cout,), Source): a 1x1 convolution of a SECOND tensor at the output
+    resolution whose products are summed into the same accumulators - a BasicBlock's conv2 together with the Tree's
+    `project` of the pooled input, which the reference adds as conv2's residual (dla.py:96-107, 56-62).  Its k-steps
+    follow the 3x3 part (slots: source 1, tap (0, 0)), the biases add, one 2^s covers both weight sets;
+    PackedConv.proj_k = Cp.  cf_conv3x3_proj_f16x3 runs it, the generic slot kernel runs the same table."""
     co, ci, kh, kw = weight.shape
     assert ci == sum(s.channels for s in sources), (ci, [s.channels for s in sources])
     pad = (kh - 1) // 2 * dilation if pad is None else pad
@@ -184,11 +191,20 @@ def pack_conv_f16(weight, bias, sources: Sequence[Source], stride=1, pad=None, d
         while len(slots) % 4:
             slots.append([0, 0, 0, -1])
             cols.append((-1, 0, 0))
+    if proj is not None:
+        pw, pb, ps = proj
+        assert patch and stride == 1 and len(slots) % 4 == 0, "a projection rides on a slice-major stride-1 3x3 packing"
+        assert tuple(pw.shape) == (co, ps.channels, 1, 1) and ps.channels % 32 == 0 and ps.stride % 8 == 0 and ps.c_base % 8 == 0
+        slots = slots + [[1, 0, 0, ps.c_base + 8 * g] for g in range(ps.channels // 8)]
+        cols = cols + [(8 * g, -1, -1) for g in range(ps.channels // 8)]
+        bias = bias + pb
     k_pad = len(slots) * 8
     w = torch.zeros(n_pad, k_pad, dtype=torch.float64)
     wf = weight.double()
     for j, (c0, r, q) in enumerate(cols):
-        if c0 >= 0:
+        if c0 >= 0 and r < 0:
+            w[:co, 8 * j:8 * j + 8] = proj[0].double()[:, c0:c0 + 8, 0, 0]
+        elif c0 >= 0:
             w[:co, 8 * j:8 * j + 8] = wf[:, c0:c0 + 8, r, q]
     wmax = float(w.abs().max())
     s_exp = int(torch.floor(torch.log2(torch.tensor(16384.0 / wmax)))) if wmax > 0 else 0
@@ -203,6 +219,9 @@ def pack_conv_f16(weight, bias, sources: Sequence[Source], stride=1, pad=None, d
                     co, n_pad, k_pad, kh, stride, pad, tuple(s.channels for s in sources))
     pc.out_scale = 2.0 ** -(s_exp + 4)
     pc.patch = patch
+    if proj is not None:
+        pc.real_cin = (sources[0].channels, proj[2].channels)
+        pc.proj_k = proj[2].channels
     return pc
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 4 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx, cf_dcn_args.out_mx */
+#define CF_ABI_VERSION 5 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx, cf_dcn_args.out_mx; 5: cf_conv3x3_proj_f16x3 */
 
 #define CF_OK 0
 #define CF_EINVAL (-22)
@@ -138,6 +138,19 @@ int cf_conv3x3_f16x3(const cf_conv_args* a, void* stream);
  * chip: it is split to fp16 hi / lo into LDS as the B operand of the Root's GEMM, whose products and order are those of
  * cf_conv2d_f16x3 - so the result equals the two launches bit for bit, which is what runs for every other shape. */
 int cf_conv3x3_root_f16x3(const cf_conv_args* conv, const cf_conv_args* root, const int32_t* root_channels, void* stream);
+
+/* (ABI 5) cf_conv3x3_proj_f16x3: BasicBlock.conv2 of the sub-tree that opens a DLA level TOGETHER WITH the Tree's `project`
+ * (1x1 convolution + BN of the 2x2-max-pooled level input), which the reference computes as a tensor and hands to the
+ * block as its residual (model/networks/dla.py:96-107 Tree.forward: bottom = downsample(x); residual = project(bottom);
+ * x1 = tree1(x, residual); dla.py:56-62 BasicBlock: out = bn2(conv2(.)) + residual; relu):
+ *   out = act( conv3x3(src[0], W2) + W_p . src[1] + (b2 + b_p) )
+ * One argument block as for cf_conv3x3_f16x3 with n_src = 2: src[0] = the 3x3 input, src[1] = the pooled tensor (same
+ * B, H, W as the output), weights = packing.pack_conv_f16(proj=...) - the projection's k-steps (slots: source 1, tap
+ * (0, 0)) behind the slice-major 3x3 part, both scaled by one 2^s, bias = the sum.  `src_channels` (host array, 2
+ * entries) = the real channels of the two sources (multiples of 32).  The projection's products go into the same
+ * accumulators, last: no residual tensor, one launch less per DLA level.  A geometry no patch tiling fits runs
+ * cf_conv2d_f16x3 on the same slot table (the same products in the same order: the same bits). */
+int cf_conv3x3_proj_f16x3(const cf_conv_args* a, const int32_t* src_channels, void* stream);
 
 /* cf_split_bf16: fp32 NHWC [M][in_stride] (C used) -> split-bf16 [M][2][Cs], channels C..Cs-1 zero. */
 int cf_split_bf16(const float* x, void* out, long M, int C, int in_stride, int Cs, void* stream);

@@ -27,7 +27,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in cf_hip.h but not exported by libcfhip.so"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes binding"
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.cf_abi_version() == 4
+    assert lib.cf_abi_version() == 5
     assert lib.cf_topk_workspace_bytes(16, 100) == 16 * 16 * 100 * 8
     assert lib.cf_topk_workspace_bytes_nms(16, 10, 112, 200, 100) == 16 * 16 * 100 * 8 + 16 * 10 * 112 * 200 * 4
 

@@ -743,6 +743,66 @@ def test_conv3x3_root_fused_equals_two_launches(dev, C_, B, H, W, kids, fused):
     assert err < 2e-6, err
 
 
+@pytest.mark.parametrize("B,Cp,C_,H,W,exact", [
+    (2, 32, 64, 112, 200, True),        # level2.tree1.conv2 + level2.project at the bench size: tiled, a 32-channel (half) piece
+    (8, 64, 128, 56, 100, True),        # level3.tree1: flat 128-pixel runs, two waves per pixel group share one piece
+    (8, 128, 256, 28, 50, True),        # level4.tree1: four waves per pixel group, two pieces
+    (8, 256, 512, 14, 25, False),       # level5: K split over wave pairs, four pieces in one round
+    (16, 128, 256, 28, 50, True),       # ... 8 waves (two pixel groups per channel group)
+    (1, 32, 64, 112, 200, True),        # one frame: the one-round half tiles (32 pixels per wave)
+    (1, 64, 128, 56, 100, True),
+    (1, 128, 256, 28, 50, True),
+    (1, 256, 512, 14, 25, False),
+    (12, 64, 128, 37, 41, True),        # ragged last run, image borders inside a run
+    (3, 96, 64, 45, 67, True),          # one and a half pieces for one wave
+    (2, 320, 256, 31, 23, True),        # five pieces for four waves: a second round with one piece
+    (2, 64, 128, 112, 200, True),       # level 3 of a high-resolution input: 8 x 16 tiles
+    (20, 32, 64, 5, 300, True),         # too wide for the patch: the slot kernel runs the same table
+])
+def test_conv3x3_proj_one_launch(dev, B, Cp, C_, H, W, exact):
+    """cf_conv3x3_proj_f16x3: BasicBlock conv2 and the Tree's project (1x1 convolution of the pooled level input, the block's
+    residual in the reference: dla.py:96-107, 56-62) summed in the same accumulators - fp32-level accuracy against float64,
+    as close to it as the two launches it replaces, and (where the K loop is not split over waves) the very bits of the
+    slot kernel run on the same slot table."""
+    from centerfusiondetect3d_amd import ops, packing
+    t, pooled = F.relu(rnd(B, C_, H, W, seed=1)) * 2, F.relu(rnd(B, Cp, H, W, seed=2)) * 2
+    w2, b2 = rnd(C_, C_, 3, 3, seed=3, scale=(C_ * 9) ** -0.5), rnd(C_, seed=4)
+    wp, bp = rnd(C_, Cp, 1, 1, seed=5, scale=Cp ** -0.5), rnd(C_, seed=6)
+    ref = F.relu(F.conv2d(t.double(), w2.double(), b2.double(), 1, 1) + F.conv2d(pooled.double(), wp.double(), bp.double()))
+    pc = packing.pack_conv_f16(w2, b2, [packing.Source(C_, C_)], proj=(wp, bp, packing.Source(Cp, Cp))).to(dev)
+    assert pc.patch and pc.proj_k == Cp and pc.k_pad == 9 * C_ + Cp and pc.real_cin == (C_, Cp)
+    td, pd = nhwc(t).to(dev), nhwc(pooled).to(dev)
+    out = ops.conv3x3_proj_f16x3(pc, td, pd)
+    err = float((nchw(out).cpu().double() - ref).abs().max() / ref.abs().max())
+    # the two launches of the unfused plan: project -> residual tensor -> conv2 + residual + ReLU
+    pcp = packing.pack_conv_f16(wp, bp, [packing.Source(Cp, Cp)]).to(dev)
+    pc2 = packing.pack_conv_f16(w2, b2, [packing.Source(C_, C_)]).to(dev)
+    res = ops.conv2d_f16x3(pcp, [pd], B, H, W, act=0)
+    two = ops.conv2d_f16x3(pc2, [td], B, H, W, act=1, residual=res)
+    err2 = float((nchw(two).cpu().double() - ref).abs().max() / ref.abs().max())
+    print(f"[conv3x3+proj] {C_}+{Cp} {H}x{W}: max|err|/max|ref| = {err:.2e} (two launches {err2:.2e})")
+    assert err < 1.5e-6 and err < 2 * err2 + 2e-7, (err, err2)
+    if exact:
+        slot = ops.conv2d_f16x3(pc, [td, pd], B, H, W, act=1, patch=False)
+        assert torch.equal(out, slot)
+
+
+def test_conv3x3_proj_refuses_what_it_cannot_run(dev):
+    from centerfusiondetect3d_amd import ops, packing, _lib
+    w2, b2, wp, bp = rnd(64, 64, 3, 3, seed=1), rnd(64, seed=2), rnd(64, 32, 1, 1, seed=3), rnd(64, seed=4)
+    pc = packing.pack_conv_f16(w2, b2, [packing.Source(64, 64)], proj=(wp, bp, packing.Source(32, 32))).to(dev)
+    plain = packing.pack_conv_f16(w2, b2, [packing.Source(64, 64)]).to(dev)
+    t, pd = torch.zeros(1, 8, 8, 64, device=dev), torch.zeros(1, 8, 8, 32, device=dev)
+    with pytest.raises(AssertionError):
+        ops.conv3x3_proj_f16x3(plain, t, pd)                    # weights without a projection part
+    a = ops.conv_args(pc, [t, pd], [64, 32], 1, 8, 8, torch.empty(1, 8, 8, 64, device=dev), 64, 1, None, 0, 0, None, 0, False)
+    import ctypes as C
+    bad = (C.c_int32 * 2)(64, 64)                               # channel counts that do not add up to K_pad
+    assert _lib.load().cf_conv3x3_proj_f16x3(C.byref(a), bad, None) != 0
+    with pytest.raises(AssertionError):                         # a projection needs the slice-major stride-1 packing
+        packing.pack_conv_f16(w2, b2, [packing.Source(64, 64)], stride=2, proj=(wp, bp, packing.Source(32, 32)))
+
+
 def test_conv2d_f16x3_root_concat(dev):
     from centerfusiondetect3d_amd import ops, packing
     B, H, W = 2, 14, 25

@@ -54,6 +54,37 @@ def test_pack_conv_slot_table_is_a_convolution(ci_list, strides, k, stride):
     np.testing.assert_allclose(emulate_igemm(pc, srcs, stride), ref, rtol=1e-5, atol=1e-5)
 
 
+def test_pack_conv_f16_with_projection_is_conv_plus_1x1():
+    """packing.pack_conv_f16(proj=...): the slot table + the fragment-packed fp16 hi/lo weights, emulated in numpy, give
+    conv3x3(t) + conv1x1(pooled) + both biases (what the reference computes as bn2(conv2(.)) + project(bottom):
+    dla.py:96-107, 56-62); the projection's slots (source 1, tap (0, 0)) follow the slice-major 3x3 part."""
+    g = torch.Generator().manual_seed(5)
+    C_, Cp, B, H, W = 64, 32, 1, 5, 6
+    w2, b2 = torch.randn(C_, C_, 3, 3, generator=g) * 0.05, torch.randn(C_, generator=g)
+    wp, bp = torch.randn(C_, Cp, 1, 1, generator=g) * 0.3, torch.randn(C_, generator=g)
+    pc = packing.pack_conv_f16(w2, b2, [packing.Source(C_, C_)], proj=(wp, bp, packing.Source(Cp, Cp)))
+    assert pc.patch and pc.proj_k == Cp and pc.k_pad == 9 * C_ + Cp and pc.real_cin == (C_, Cp)
+    slots = pc.slots.numpy()
+    assert (slots[:9 * C_ // 8, 0] == 0).all() and (slots[9 * C_ // 8:, 0] == 1).all() and (slots[9 * C_ // 8:, 1:3] == 0).all()
+    # fragments [rt][ks][plane][lane = 32 h + i][8] -> dense (N, K): W[32 rt + i][16 ks + 8 h + j]
+    f = pc.weight.float().numpy().astype(np.float64)
+    dense = (f[:, :, 0] + f[:, :, 1]).reshape(pc.n_pad // 32, pc.k_pad // 16, 2, 32, 8).transpose(0, 3, 1, 2, 4).reshape(pc.n_pad, pc.k_pad)
+    dense *= pc.out_scale * 16.0                                    # 2^-s
+    t, pooled = torch.randn(B, H, W, C_, generator=g).numpy(), torch.randn(B, H, W, Cp, generator=g).numpy()
+    srcs = [t, pooled]
+    out = np.zeros((B, H, W, pc.n_pad))
+    for j, (src, dy, dx, c_off) in enumerate(slots.tolist()):
+        x = np.zeros((B, H, W, 8))
+        ys, xs = np.arange(H) + dy, np.arange(W) + dx
+        oky, okx = (ys >= 0) & (ys < H), (xs >= 0) & (xs < W)
+        x[np.ix_(np.arange(B), np.nonzero(oky)[0], np.nonzero(okx)[0])] = srcs[src][:, ys[oky]][:, :, xs[okx]][..., c_off:c_off + 8]
+        out += x @ dense[:, 8 * j:8 * j + 8].T
+    out += pc.bias.numpy()
+    ref = (F.conv2d(torch.from_numpy(t).permute(0, 3, 1, 2).double(), w2.double(), b2.double(), 1, 1)
+           + F.conv2d(torch.from_numpy(pooled).permute(0, 3, 1, 2).double(), wp.double(), bp.double())).permute(0, 2, 3, 1).numpy()
+    assert np.abs(out[..., :C_] - ref).max() < 2e-6 * np.abs(ref).max()
+
+
 def test_fold_bn_and_pack_dcn():
     g = torch.Generator().manual_seed(1)
     w, b = torch.randn(8, 32, 3, 3, generator=g), torch.randn(8, generator=g)

@@ -1,6 +1,7 @@
 """Dev (GPU box): randomised check of the rule behind SURVEY 8(e) - a shard of a batch reproduces the full batch BIT FOR BIT -
 on the kernel families whose tile shape follows the launch size (conv3x3 LDS-patch kernel: half-height tiles while the
-grid fits one round - stride 1, stride 2 and the fused conv2 + Root launch, which also switches between one and two launches;
+grid fits one round - stride 1, stride 2, the fused conv2 + Root launch, which also switches between one and two launches,
+and conv2 + project;
 DCN: 64-pixel tiles for 64-output layers).  Random (B, H, W, Cin, Cout) around the dispatch thresholds;
 every frame alone and every pair must equal its slice of the full-batch result, and the full batch must agree with float64.
     python tools/sweep_shard_bits.py [n_cases] [seed]"""
@@ -66,6 +67,19 @@ for case in range(n_cases):
         for lo, hi in pairs:
             part, _ = ops.conv3x3_root_f16x3(pc, pcr, xd[lo:hi].contiguous(), x1[lo:hi].contiguous(), [c[lo:hi].contiguous() for c in chd])
             ok_r &= bool(torch.equal(part, fullr[lo:hi]))
+    # ---- conv2 + the Tree's project of the pooled input in one launch (round 5): 64+ output channels, Cin of the 3x3 = Cout
+    ok_p = True
+    if Co != 27 and Ci == Co:
+        Cp = int(rs.choice([32, 64, 96, 128, 256]))
+        wpj, bpj = torch.randn(Co, Cp, 1, 1, generator=g) * Cp ** -0.5, torch.randn(Co, generator=g)
+        pooled = F.relu(torch.randn(B, Cp, H, W, generator=g)) * 2
+        pcj = packing.pack_conv_f16(w, b, [packing.Source(Ci, Ci)], proj=(wpj, bpj, packing.Source(Cp, Cp))).to(dev)
+        pld = nhwc(pooled).to(dev)
+        fullp = ops.conv3x3_proj_f16x3(pcj, xd, pld)
+        refp = F.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1) + F.conv2d(pooled.double(), wpj.double(), bpj.double()))
+        ok_p = float((fullp.permute(0, 3, 1, 2).cpu().double() - refp).abs().max() / refp.abs().max()) < 1.5e-6
+        for lo, hi in pairs:
+            ok_p &= bool(torch.equal(ops.conv3x3_proj_f16x3(pcj, xd[lo:hi].contiguous(), pld[lo:hi].contiguous()), fullp[lo:hi]))
     # ---- DCN (Cout padded to 32s by the packer)
     ok_d = True
     if Co != 27:
@@ -79,7 +93,7 @@ for case in range(n_cases):
             partd = ops.dcn_v2_fused(pd, xd[lo:hi].contiguous(), om[lo:hi].contiguous())
             ok_d &= bool(torch.equal(partd, fulld[lo:hi]))
     print(f"case {case:3d}: B={B} {Ci}->{Co} {H}x{W}: conv err {err:.1e} {'ok' if ok else 'MISMATCH'}; stride 2 {'ok' if ok_s else 'MISMATCH'}; "
-          f"conv2+root {'ok' if ok_r else 'MISMATCH'}; dcn {'ok' if ok_d else 'MISMATCH'}", flush=True)
-    bad += (not ok) + (not ok_d) + (not ok_s) + (not ok_r)
+          f"conv2+root {'ok' if ok_r else 'MISMATCH'}; conv2+project {'ok' if ok_p else 'MISMATCH'}; dcn {'ok' if ok_d else 'MISMATCH'}", flush=True)
+    bad += (not ok) + (not ok_d) + (not ok_s) + (not ok_r) + (not ok_p)
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
