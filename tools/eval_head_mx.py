@@ -72,6 +72,8 @@ variants = {
   "mx all, own lo max": (mxo, mxo, mxo),
   "mx all, weights refined (2.0 passes)": (mxr, mxr, mxr),
   "mxr first, bf16x3 rest": (mxr, mm_bf16x3, mm_bf16x3),
+  "mx first, mxr hidden, bf16x3 out": (mxo, mxr, mm_bf16x3),
+  "mxr first, mxr hidden, bf16x3 out": (mxr, mxr, mm_bf16x3),
 }
 sel = sys.argv[2:] or list(variants)
 with torch.no_grad():
