@@ -151,9 +151,14 @@ def test_forward_matches_reference_golden(dev, golden_dir, tag, radar, B, H, W):
             assert torch.equal(out2[0][k], y[k]), f"{k}: forward is not deterministic"
 
 
-@pytest.mark.parametrize("flags", [dict(heads_mx=False), dict(pack_mx_fused=False)], ids=["heads_bf16x3", "separate_pack_pass"])
+@pytest.mark.parametrize("flags", [dict(heads_mx=False), dict(pack_mx_fused=False), dict(proj_fuse=False),
+                                   dict(conv_patch=False)],
+                         ids=["heads_bf16x3", "separate_pack_pass", "project_launches", "slot_kernels_only"])
 def test_forward_matches_reference_golden_on_the_switchable_head_paths(dev, golden_dir, flags):
-    """the A/B switches of the heads' first layer keep working at module level: `heads_mx = False` (bf16x3, the round-4
+    """(also: `proj_fuse = False` - the four `project` convolutions as their own launches with residual tensors, bench.py
+    --no-proj-fuse - and `conv_patch = False` - every f16x3 convolution on the slot kernel, conv2 + project from its two-source
+    slot table - against the same goldens.)
+    the A/B switches of the heads' first layer keep working at module level: `heads_mx = False` (bf16x3, the round-4
     arithmetic - bench.py --heads-bf16x3) against the reference's golden outputs with the same tolerance, and
     `pack_mx_fused = False` (cf_pack_feat_mx as its own launch instead of the DCN epilogue): same tolerance, and bit-identical to the
     default wherever the producing DCN does not split K"""
@@ -170,6 +175,9 @@ def test_forward_matches_reference_golden_on_the_switchable_head_paths(dev, gold
         y = m(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))[0]
         ref = _model(True, dev, (H, W))(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))[0]
     assert m._mx_active == bool(flags.get("heads_mx", True))
+    names = {n for plan in m._all_plans() for n in plan.step_index}
+    assert any(n.endswith(".project") for n in names) == (not flags.get("proj_fuse", True))
+    assert any(n.endswith(".conv2+project") for n in names) == flags.get("proj_fuse", True)
     for k, v in y.items():
         if k == "calib":
             continue
