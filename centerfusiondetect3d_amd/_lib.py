@@ -58,7 +58,7 @@ class StemArgs(C.Structure):
                 ("w_base", _f), ("b_base", _f), ("scale_base", C.c_float),
                 ("w_level0", _f), ("b_level0", _f), ("scale_level0", C.c_float),
                 ("w_level1", _f), ("b_level1", _f), ("scale_level1", C.c_float),
-                ("out", _f)]
+                ("out", _f), ("out_pool", _f)]
 
 
 class DecodeArgs(C.Structure):

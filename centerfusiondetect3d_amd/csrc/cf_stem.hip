@@ -49,6 +49,7 @@ struct StemK {
   const float* b_l1;              // 32
   float s_base, s_l0, s_l1;       // 2^-(s+4) per layer
   float* out;                     // fp32 NHWC (B, H/2, W/2, 32)
+  float* out_pool;                // optional: its 2x2 / stride 2 max-pool, fp32 NHWC (B, H/4, W/4, 32)
   int tiles_x, tiles_y;
 };
 
@@ -274,11 +275,23 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int y = oy0 + oy[u], x = ox0 + ox[u];
-      if (y < H1 && x < W1) {
-        f32x4v v;
+      f32x4v v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf((accm[u][e] + accs[u][e]) * p.s_l1 + bias_1[e], 0.0f);
-        *reinterpret_cast<f32x4v*>(p.out + (((size_t)b * H1 + y) * W1 + x) * 32 + 16 * rt + 4 * kg) = v;
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf((accm[u][e] + accs[u][e]) * p.s_l1 + bias_1[e], 0.0f);
+      if (y < H1 && x < W1) *reinterpret_cast<f32x4v*>(p.out + (((size_t)b * H1 + y) * W1 + x) * 32 + 16 * rt + 4 * kg) = v;
+      // the level-2 Tree max-pools this map 2x2 (dla.py:96 downsample) - the only reader of that pool is its `project`: the
+      // 16 pixels of the MFMA tile are two rows of 8, so a pool window is lanes {c, c + 1, c + 8, c + 9} of one k group:
+      // two lane exchanges, and the even-column lanes of the upper row write the pooled pixel (floor semantics at odd sizes)
+      if (p.out_pool) {
+        f32x4v m = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          m[e] = fmaxf(m[e], __shfl_xor(m[e], 1));
+          m[e] = fmaxf(m[e], __shfl_xor(m[e], 8));
+        }
+        const int H2 = H1 / 2, W2 = W1 / 2, yp = y >> 1, xp = x >> 1;
+        if ((col & 9) == 0 && yp < H2 && xp < W2)
+          *reinterpret_cast<f32x4v*>(p.out_pool + (((size_t)b * H2 + yp) * W2 + xp) * 32 + 16 * rt + 4 * kg) = m;
       }
     }
   }
@@ -301,6 +314,7 @@ extern "C" int cf_stem_fused(const cf_stem_args* a, void* stream) {
   k.b_base = a->b_base; k.b_l0 = a->b_level0; k.b_l1 = a->b_level1;
   k.s_base = a->scale_base; k.s_l0 = a->scale_level0; k.s_l1 = a->scale_level1;
   k.out = a->out;
+  k.out_pool = a->out_pool;
   k.tiles_x = (a->W / 2 + ST_T1 - 1) / ST_T1;
   k.tiles_y = (a->H / 2 + ST_T1 - 1) / ST_T1;
   const long blocks = (long)k.tiles_x * k.tiles_y * a->B;

@@ -441,7 +441,11 @@ class _Plan:
             if "base.stem" in pk:
                 # base_layer + level0 + level1 in one launch; the full-resolution maps stay in LDS
                 y0, y1 = None, buf(B, H // 2, W // 2, 32)
-                self.stem = ops.stem_args(pk["base.stem"], None, y1, shape=(B, 3, H, W))
+                # ... and the level-2 Tree's 2x2 max-pool of that map (dla.py:96) comes out of the same launch
+                y1p = buf(B, H // 4, W // 4, 32) if model.stem_pool else None
+                if y1p is not None:
+                    pooled[y1.data_ptr()] = y1p
+                self.stem = ops.stem_args(pk["base.stem"], None, y1, shape=(B, 3, H, W), out_pool=y1p)
                 self.keep.append(self.stem)
                 self.step_index["base.stem"] = self.in_step
                 self.step_flops["base.stem"] = 2.0 * B * H * W * (16 * 147 + 16 * 144 + 32 * 144 / 4)
@@ -774,6 +778,7 @@ class DLASeg(nn.Module):
         self.use_graph = False   # replay the forward as ONE captured HIP graph (inputs / outputs staged through
                                  # static buffers) instead of ~100 launches from Python (_forward_graph)
         self.stem_fused = True   # with conv_f16: base_layer + level0 + level1 in one launch (cf_stem.hip)
+        self.stem_pool = True    # ... which also writes the level-2 Tree's max-pool of its output (one launch less per trunk)
         self.conv_patch = True   # 3x3 stride-1 f16x3 convs: LDS patch reuse (cf_conv3x3_f16.hip)
         self.root_fuse = True    # one-level Trees without children: tree2.conv2 + Root as one step (cf_conv3x3_root_f16x3)
         self.proj_fuse = True    # the sub-tree that opens a level: `project` of the pooled input as k-steps of tree1.conv2

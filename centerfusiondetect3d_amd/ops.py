@@ -596,8 +596,9 @@ def pillar_expand(pc_2d, pc_3d, counts, calib, trans, out_hw, pillar_dims=(1.5, 
     return (pc_dep, keep, xy) if want_aux else pc_dep
 
 
-def stem_args(ps, x, out, shape=None) -> _lib.StemArgs:
-    """x may be None with shape=(B, C, H, W) given: the image pointer is then patched in per call."""
+def stem_args(ps, x, out, shape=None, out_pool=None) -> _lib.StemArgs:
+    """x may be None with shape=(B, C, H, W) given: the image pointer is then patched in per call.
+    out_pool: optional (B, H/4, W/4, 32) buffer for the 2x2 max-pool of the level1 map."""
     a = _lib.StemArgs()
     B, Cc, H, W = shape if x is None else x.shape
     a.x, a.B, a.C, a.H, a.W = (_lib.ptr(x), B, Cc, H, W)
@@ -605,16 +606,18 @@ def stem_args(ps, x, out, shape=None) -> _lib.StemArgs:
     a.w_level0, a.b_level0, a.scale_level0 = ps.w_level0.data_ptr(), ps.b_level0.data_ptr(), ps.scale_level0
     a.w_level1, a.b_level1, a.scale_level1 = ps.w_level1.data_ptr(), ps.b_level1.data_ptr(), ps.scale_level1
     a.out = out.data_ptr()
+    a.out_pool = _lib.ptr(out_pool)
     return a
 
 
-def stem_fused(ps, x, out=None):
-    """images (B, C<=3, H, W) fp32 NCHW -> level1 map (B, H/2, W/2, 32) fp32 NHWC (packing.pack_stem)."""
-    _need_cuda(x)
+def stem_fused(ps, x, out=None, out_pool=None):
+    """images (B, C<=3, H, W) fp32 NCHW -> level1 map (B, H/2, W/2, 32) fp32 NHWC (packing.pack_stem); out_pool: also its
+    MaxPool2d(2, 2), (B, H/4, W/4, 32)."""
+    _need_cuda(x, out_pool)
     B, Cc, H, W = x.shape
     if out is None:
         out = torch.empty((B, H // 2, W // 2, 32), device=x.device, dtype=torch.float32)
-    a = stem_args(ps, x.contiguous(), out)
+    a = stem_args(ps, x.contiguous(), out, out_pool=out_pool)
     _lib.check(_lib.load().cf_stem_fused(C.byref(a), _lib.stream_ptr()), "cf_stem_fused")
     return out
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 5 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx, cf_dcn_args.out_mx; 5: cf_conv3x3_proj_f16x3 */
+#define CF_ABI_VERSION 5 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx, cf_dcn_args.out_mx; 5: cf_conv3x3_proj_f16x3, cf_stem_args.out_pool */
 
 #define CF_OK 0
 #define CF_EINVAL (-22)
@@ -96,6 +96,8 @@ typedef struct cf_stem_args {
   const void* w_level0; const float* b_level0; float scale_level0;
   const void* w_level1; const float* b_level1; float scale_level1;
   float* out;                     /* fp32 NHWC (B, H/2, W/2, 32)                               */
+  float* out_pool;                /* (ABI 5) optional: MaxPool2d(2, 2) of `out`, fp32 NHWC (B, H/4, W/4, 32) - the level-2
+                                     Tree's downsample (dla.py:96), written from the same registers; NULL = not written */
 } cf_stem_args;
 int cf_stem_fused(const cf_stem_args* a, void* stream);
 

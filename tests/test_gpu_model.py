@@ -151,12 +151,12 @@ def test_forward_matches_reference_golden(dev, golden_dir, tag, radar, B, H, W):
             assert torch.equal(out2[0][k], y[k]), f"{k}: forward is not deterministic"
 
 
-@pytest.mark.parametrize("flags", [dict(heads_mx=False), dict(pack_mx_fused=False), dict(proj_fuse=False),
+@pytest.mark.parametrize("flags", [dict(heads_mx=False), dict(pack_mx_fused=False), dict(proj_fuse=False, stem_pool=False),
                                    dict(conv_patch=False)],
-                         ids=["heads_bf16x3", "separate_pack_pass", "project_launches", "slot_kernels_only"])
+                         ids=["heads_bf16x3", "separate_pack_pass", "project_and_pool_launches", "slot_kernels_only"])
 def test_forward_matches_reference_golden_on_the_switchable_head_paths(dev, golden_dir, flags):
-    """(also: `proj_fuse = False` - the four `project` convolutions as their own launches with residual tensors, bench.py
-    --no-proj-fuse - and `conv_patch = False` - every f16x3 convolution on the slot kernel, conv2 + project from its two-source
+    """(also: `proj_fuse = False`, `stem_pool = False` - the four `project` convolutions and the level-2 max-pool as their own
+    launches, bench.py --no-proj-fuse --no-stem-pool - and `conv_patch = False` - every f16x3 convolution on the slot kernel, conv2 + project from its two-source
     slot table - against the same goldens.)
     the A/B switches of the heads' first layer keep working at module level: `heads_mx = False` (bf16x3, the round-4
     arithmetic - bench.py --heads-bf16x3) against the reference's golden outputs with the same tolerance, and

@@ -874,7 +874,7 @@ def test_dcn_v2_f16x3_checks_the_workspace_size(dev):
 
 
 # ----------------------------------------------------------------------------------- fused stem
-@pytest.mark.parametrize("B,C,H,W", [(2, 3, 64, 96), (1, 3, 16, 16), (1, 3, 34, 50), (3, 1, 18, 130), (1, 3, 160, 224)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 3, 64, 96), (1, 3, 16, 16), (1, 3, 34, 50), (3, 1, 18, 130), (1, 3, 160, 224), (1, 3, 448, 800)])
 def test_stem_fused(dev, B, C, H, W):
     """base_layer 7x7 + level0 3x3 + level1 3x3/2 (+ bias + ReLU each) in one launch against float64
     torch: per-layer zero padding at the image border, ragged level1 tiles, fp32-level accuracy."""
@@ -895,6 +895,12 @@ def test_stem_fused(dev, B, C, H, W):
     err32 = float((t32.double() - ref).abs().max() / ref.abs().max())
     print(f"[stem] {B}x{C}x{H}x{W}: max|err|/max|ref| = {err:.2e} (torch fp32 chain: {err32:.2e})")
     assert err < 2e-6, err
+    # the pooled second output (the level-2 Tree's MaxPool2d(2, 2) of this map, dla.py:96): the very values cf_maxpool2x2 /
+    # torch give on the first output, floor semantics at odd sizes, nothing written outside; the first output unchanged
+    pool = torch.full((B, H // 4, W // 4, 32), float("nan"), device=dev)
+    out2 = ops.stem_fused(ps, x.to(dev), out_pool=pool)
+    assert torch.equal(out2, out)
+    assert torch.equal(nchw(pool), F.max_pool2d(nchw(out), 2, 2))
 
 
 # ------------------------------------------------------------------------- image pre-processing
