@@ -151,7 +151,8 @@ int cf_conv3x3_root_f16x3(const cf_conv_args* conv, const cf_conv_args* root, co
  * (0, 0)) behind the slice-major 3x3 part, both scaled by one 2^s, bias = the sum.  `src_channels` (host array, 2
  * entries) = the real channels of the two sources (multiples of 32).  The projection's products go into the same
  * accumulators, last: no residual tensor, one launch less per DLA level.  A geometry no patch tiling fits runs
- * cf_conv2d_f16x3 on the same slot table (the same products in the same order: the same bits). */
+ * cf_conv2d_f16x3 on the same slot table (the same products in the same order; the same bits wherever the patch tiling
+ * does not split K over waves - maps of at most 512 pixels with 256+ channels do, as in cf_conv3x3_f16x3). */
 int cf_conv3x3_proj_f16x3(const cf_conv_args* a, const int32_t* src_channels, void* stream);
 
 /* cf_split_bf16: fp32 NHWC [M][in_stride] (C used) -> split-bf16 [M][2][Cs], channels C..Cs-1 zero. */
