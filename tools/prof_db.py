@@ -32,9 +32,9 @@ agg = defaultdict(lambda: [0, 0.0])
 for n, s, e in last:
     agg[short(n)][0] += 1
     agg[short(n)][1] += (e - s) / 1e6
-print(f"{'kernel':70s} {'calls':>5s} {'ms':>9s} {'%':>6s}")
+print(f"{'kernel':84s} {'calls':>5s} {'ms':>9s} {'%':>6s}")
 for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print(f"{k[:70]:70s} {n:5d} {ms:9.3f} {100 * ms / busy:6.1f}")
+    print(f"{k[:84]:84s} {n:5d} {ms:9.3f} {100 * ms / busy:6.1f}")
 if "--timeline" in sys.argv:
     t0 = last[0][1]
     for n, s, e in last:
