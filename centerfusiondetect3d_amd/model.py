@@ -558,9 +558,9 @@ class _Plan:
                                         for h in names)
             self.add_step((self.lib.cf_head_tail, C.byref(a)))
 
-        def fused_heads(name, names, srcs, strides):
+        def fused_heads(name, names, srcs, strides, pkname=None):
             """One cf_head_fused launch: 3x3 + ReLU + tail for sibling heads, hidden never in HBM."""
-            hd = [dict(pk[name][h], act=act_of(h)) for h in names]
+            hd = [dict(pk[pkname or name][h], act=act_of(h)) for h in names]
             f = ops.head_fused_args(srcs, strides, hd[0].get("slots"), hd[0].get("k_pad", 0), B, h4, w4, hd)
             self.keep.append(f)
             for n, h in enumerate(names):
@@ -572,7 +572,26 @@ class _Plan:
             self.add_step((self.lib.cf_head_fused, C.byref(f)))
 
         fuse_all = bf and bool(model.heads_fused)
-        if fuse_all:
+        # Two lanes for the decoder's index kernels (model.heads_lanes, fused heads): behind the primary launch the side stream
+        # runs the decoder's NMS + top-k (handed to decode.py through the heat map tensor, see run()) beside the frustum
+        # path and the secondary launch, instead of alone on the chip behind the last head launch.  (Splitting the primary
+        # launch in two so that the frustum path's top-k could go there as well costs the head launches more than both
+        # top-k passes take: DESIGN.md section 9.)
+        self.peaks_step = None
+        split = fuse_all and bool(model.heads_lanes) and primary[0] == "heatmap"
+        if split:
+            self.use_lanes = True
+            fused_heads("tails.primary", primary, [feat_in], [64])
+            ev_a = self.new_event()
+            self.ctl("rec", 0, ev_a)
+            self.lane = 1
+            self.ctl("wait", 1, ev_a)
+            self.pk_ws = buf(max(1, self.lib.cf_topk_workspace_bytes_nms(B, heads["heatmap"], h4, w4, K)), dtype=torch.uint8)
+            self.peaks_step = len(self.steps); self.add_step(None)
+            self.ev_peaks = self.new_event()
+            self.ctl("rec", 1, self.ev_peaks)
+            self.lane = 0
+        elif fuse_all:
             fused_heads("tails.primary", primary, [feat_in], [64])
         elif bf:
             fused_tails("tails.primary", primary, hid, hs)
@@ -580,17 +599,19 @@ class _Plan:
             for h in primary:
                 head_out(h, hid, hs)
         if radar:
+            self.pc_hm4 = None if bf else buf(B, h4, w4, 4)
+            self.pc_hm8 = buf(B, h4, w4, 2, 8, dtype=torch.bfloat16) if bf else None
             self.tk_scores = buf(B, K)
             self.tk_inds = buf(B, K, dtype=torch.int32)
             self.tk_cls = buf(B, K, dtype=torch.int32)
-            self.pc_hm4 = None if bf else buf(B, h4, w4, 4)
-            self.pc_hm8 = buf(B, h4, w4, 2, 8, dtype=torch.bfloat16) if bf else None
             self.tk_ws = buf(max(1, self.lib.cf_topk_workspace_bytes(B, K)), dtype=torch.uint8)
             self.topk_step = len(self.steps); self.add_step(None)
             self.frustum_step = len(self.steps); self.add_step(None)
             ss = 256 * len(SECONDARY_HEADS)
             if fuse_all:
                 fused_heads("tails.secondary", SECONDARY_HEADS, [feat_in, self.pc_hm8], [64, 8])
+                if split:
+                    self.ctl("wait", 0, self.ev_peaks)
                 return
             s1 = hconv("heads.secondary.0", [feat_in, self.pc_hm8 if bf else self.pc_hm4],
                        [64, 8 if bf else 4], out_c=ss)
@@ -602,6 +623,8 @@ class _Plan:
                     hconv(f"heads.{h}.2", [s1], [ss], out=s2, out_offset=256 * n)
                     hconv(f"heads.{h}.4", [s2], [ss], out=s1, out_offset=256 * n)
                     head_out(h, s1, ss)
+        elif split:
+            self.ctl("wait", 0, self.ev_peaks)
 
     # ------------------------------------------------------------------------------------------
     def add_step(self, step):
@@ -618,11 +641,17 @@ class _Plan:
         return self.n_events - 1
 
     def _launch(self, st):
-        if self.timed:
+        """Issue the plan's steps.  With lanes (and outside a stream capture) a step runs on the caller's stream (lane 0) or
+        on the plan's side stream (lane 1), ordered by the ("rec" | "wait", event) control steps; otherwise everything runs
+        in list order on the caller's stream (the list order is a valid sequential order).  Timed steps (model.time_launch)
+        are bracketed by HIP events recorded on the stream the step runs on."""
+        lanes_on = self.use_lanes and not torch.cuda.is_current_stream_capturing()
+        timed = self.timed
+        if not lanes_on:
             for i, step in enumerate(self.steps):
                 if isinstance(step[0], str):
                     continue                                   # one stream: program order is the dependency order
-                ev = self.timed.get(i)
+                ev = timed.get(i) if timed else None
                 if ev is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -633,28 +662,27 @@ class _Plan:
                 if rc != 0:
                     _lib.check(rc, step[0].__name__)
             return
-        if not self.use_lanes or torch.cuda.is_current_stream_capturing():
-            for step in self.steps:
-                if isinstance(step[0], str):
-                    continue
-                rc = step[0](*step[1:], st)
-                if rc != 0:
-                    _lib.check(rc, step[0].__name__)
-            return
         cur = torch.cuda.current_stream(self.device)
         if getattr(self, "_side", None) is None:
             self._side = _side_streams(self.device, cur.cuda_stream, 1)[0]
             self._events = [torch.cuda.Event() for _ in range(self.n_events)]
         streams = (cur, self._side)
         ptrs = (st, self._side.cuda_stream)
-        for step, lane in zip(self.steps, self.lanes):
+        for i, (step, lane) in enumerate(zip(self.steps, self.lanes)):
             op = step[0]
             if op == "rec":
                 self._events[step[1]].record(streams[lane])
             elif op == "wait":
                 streams[lane].wait_event(self._events[step[1]])
             else:
+                ev = timed.get(i) if timed else None
+                if ev is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(streams[lane])
                 rc = op(*step[1:], ptrs[lane])
+                if ev is not None:
+                    e1.record(streams[lane])
+                    ev.append((e0, e1))
                 if rc != 0:
                     _lib.check(rc, op.__name__)
         # (every side-lane launch is waited for by a main-lane step that consumes it: the caller's stream is again
@@ -698,6 +726,19 @@ class _Plan:
         y["depth"] = new(1)
         set_out("depth", y["depth"], second=True)
         y["calib"] = calib
+        if self.peaks_step is not None:
+            # the decoder's peaks (3x3 NMS + top-K of the heat map, decode.py) are computed on the side lane beside the second
+            # primary launch and travel with the heat map tensor: decode._peaks_and_maps picks them up when K and the
+            # tensor's version still match, and computes them itself otherwise
+            peaks_on = not torch.cuda.is_current_stream_capturing()   # (a captured forward hands out copies of its maps: nothing to carry)
+            if peaks_on:
+                pk_s = torch.empty((B, self.K), device=dev, dtype=torch.float32)
+                pk_i = torch.empty((B, self.K), device=dev, dtype=torch.int32)
+                pk_c = torch.empty((B, self.K), device=dev, dtype=torch.int32)
+                self.steps[self.peaks_step] = (lib.cf_topk_peaks, y["heatmap"].data_ptr(), B, heads["heatmap"], h4, w4, self.K, 2,
+                                               pk_s.data_ptr(), pk_i.data_ptr(), pk_c.data_ptr(), self.pk_ws.data_ptr())
+            else:
+                self.steps[self.peaks_step] = (_no_launch,)
         if self.in_step is not None:
             if self.stem is not None:
                 self.stem.x = x.data_ptr()
@@ -727,8 +768,20 @@ class _Plan:
             y["depth2"] = new(1)
             set_out("depth2", y["depth2"], second=True)
         self._launch(st)
+        if self.peaks_step is not None and peaks_on:
+            hm = y["heatmap"]
+            hm._cf_peaks = (self.K, hm._version, hm.data_ptr(), pk_s, pk_i, pk_c)
+            side = getattr(self, "_side", None)
+            if side is not None:                               # (allocator: these tensors were also used on the side stream)
+                for t in (hm, pk_s, pk_i, pk_c):
+                    t.record_stream(side)
         return [y]
 
+
+
+def _no_launch(stream):
+    """a plan step that issues nothing (status 0)"""
+    return 0
 
 
 # ----------------------------------------------------------------------------------- the module
@@ -781,6 +834,8 @@ class DLASeg(nn.Module):
         self.stem_pool = True    # ... which also writes the level-2 Tree's max-pool of its output (one launch less per trunk)
         self.conv_patch = True   # 3x3 stride-1 f16x3 convs: LDS patch reuse (cf_conv3x3_f16.hip)
         self.root_fuse = True    # one-level Trees without children: tree2.conv2 + Root as one step (cf_conv3x3_root_f16x3)
+        self.heads_lanes = True  # fused heads: the decoder's NMS + top-k on a side stream beside the frustum path and the secondary
+                                 # launch (_Plan heads section), handed to decode.py with the heat map
         self.proj_fuse = True    # the sub-tree that opens a level: `project` of the pooled input as k-steps of tree1.conv2
                                  # (cf_conv3x3_proj_f16x3) instead of a launch + a residual tensor; set before the first forward
         self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)

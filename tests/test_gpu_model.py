@@ -202,6 +202,44 @@ def test_forward_matches_reference_golden_on_the_switchable_head_paths(dev, gold
                 assert torch.equal(outs[0][k], outs[1][k]), k
 
 
+def test_decoder_peaks_travel_with_the_heat_map(dev):
+    """model.heads_lanes: the forward computes the decoder's NMS + top-k on a side stream and hands it to decode.py through the
+    heat map tensor - the decoded rows must be the ones decode computes by itself, the hand-over must lapse when K differs or the
+    heat map was modified or replaced, and `heads_lanes = False` must give the same maps."""
+    from centerfusiondetect3d_amd import decode_packed, ops
+    H, W, B = 128, 160, 3
+    m = _model(True, dev, (H, W))
+    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=4, radar=True)
+    with torch.no_grad():
+        out = m(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))
+    hm = out[0]["heatmap"]
+    assert m.heads_lanes and getattr(hm, "_cf_peaks", None) is not None
+    K, ver, ptr, s_c, i_c, c_c = hm._cf_peaks
+    s_r, i_r, c_r = ops.topk_peaks(hm, K, nms=True)
+    assert torch.equal(s_c, s_r) and torch.equal(i_c, i_r) and torch.equal(c_c, c_r)
+    det_cached, _ = decode_packed([dict(out[0])], (H // 4, W // 4), K=K)
+    plain = dict(out[0]); plain["heatmap"] = hm.clone()          # a replaced tensor carries nothing
+    assert getattr(plain["heatmap"], "_cf_peaks", None) is None
+    det_plain, _ = decode_packed([plain], (H // 4, W // 4), K=K)
+    assert torch.equal(det_cached, det_plain)
+    det_k, _ = decode_packed([dict(out[0])], (H // 4, W // 4), K=K // 2)     # another K: computed afresh
+    assert torch.equal(det_k, det_plain[:, :K // 2])
+    hm.mul_(0.5)                                                  # modified in place: the version no longer matches
+    det_mod, _ = decode_packed([dict(out[0])], (H // 4, W // 4), K=K)
+    ref_mod = dict(out[0]); ref_mod["heatmap"] = hm.clone()
+    det_ref, _ = decode_packed([ref_mod], (H // 4, W // 4), K=K)
+    assert torch.equal(det_mod, det_ref) and not torch.equal(det_mod[..., 0], det_cached[..., 0])
+    m2 = _model(True, dev, (H, W))
+    m2.heads_lanes = False
+    m2.invalidate()
+    with torch.no_grad():
+        out2 = m2(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))
+    assert getattr(out2[0]["heatmap"], "_cf_peaks", None) is None
+    for k in out2[0]:
+        if k not in ("calib", "heatmap"):
+            assert torch.equal(out2[0][k], out[0][k]), k
+
+
 def test_forward_and_decode_fullres_vs_reference_samples(dev, golden_dir):
     from centerfusiondetect3d_amd import fusionDecode
     g = np.load(os.path.join(golden_dir, "model_centerfusion_fullres.npz"))

@@ -26,6 +26,8 @@ m.heads_mfma16 = not a.heads_mfma32
 m.heads_mx = not a.heads_bf16x3
 m.proj_fuse = not a.no_proj_fuse
 m.streams = 1          # per-launch event timing needs one stream
+m.lanes = False
+m.heads_lanes = False
 m = bench.synthetic_weights(m).to(dev).eval()
 images, pc_dep, calib = bench.make_inputs(a.batch, H, W, dev, 1000)
 with torch.no_grad():
