@@ -30,7 +30,11 @@ def _peaks_and_maps(outputs, K):
     # the forward may have computed exactly these peaks already, beside its own launches (model._Plan.run: the heat map tensor
     # carries them); they are used only for the very tensor they were computed from, unmodified since
     cached = getattr(heat, "_cf_peaks", None)
-    if cached is not None and cached[0] == K and cached[1] == heat._version and cached[2] == heat.data_ptr():
+    try:
+        version = heat._version
+    except RuntimeError:                                       # (an inference-mode tensor: nothing is ever attached to one)
+        version = None
+    if cached is not None and cached[0] == K and cached[1] == version and cached[2] == heat.data_ptr():
         scores, inds, classes = cached[3:]
     else:
         scores, inds, classes = ops.topk_peaks(heat, K, nms=True)

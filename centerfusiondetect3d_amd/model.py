@@ -770,7 +770,10 @@ class _Plan:
         self._launch(st)
         if self.peaks_step is not None and peaks_on:
             hm = y["heatmap"]
-            hm._cf_peaks = (self.K, hm._version, hm.data_ptr(), pk_s, pk_i, pk_c)
+            try:
+                hm._cf_peaks = (self.K, hm._version, hm.data_ptr(), pk_s, pk_i, pk_c)
+            except RuntimeError:                               # (torch.inference_mode(): no version counter to detect an in-place
+                pass                                           #  change of the heat map with - decode computes its own peaks)
             side = getattr(self, "_side", None)
             if side is not None:                               # (allocator: these tensors were also used on the side stream)
                 for t in (hm, pk_s, pk_i, pk_c):

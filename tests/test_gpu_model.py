@@ -229,6 +229,11 @@ def test_decoder_peaks_travel_with_the_heat_map(dev):
     ref_mod = dict(out[0]); ref_mod["heatmap"] = hm.clone()
     det_ref, _ = decode_packed([ref_mod], (H // 4, W // 4), K=K)
     assert torch.equal(det_mod, det_ref) and not torch.equal(det_mod[..., 0], det_cached[..., 0])
+    with torch.inference_mode():                                  # no version counter on inference tensors: nothing is attached
+        out_i = m(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))
+        assert getattr(out_i[0]["heatmap"], "_cf_peaks", None) is None
+        det_i, _ = decode_packed([dict(out_i[0])], (H // 4, W // 4), K=K)
+    assert torch.equal(det_i, det_plain)
     m2 = _model(True, dev, (H, W))
     m2.heads_lanes = False
     m2.invalidate()
