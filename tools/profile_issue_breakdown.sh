@@ -1,6 +1,6 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-OUT=gpurun_out/prof_r4_issue
+OUT=gpurun_out/prof_${1:-r5}_issue
 mkdir -p $OUT
 ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES --kernel-trace -d $OUT/a -- python3 $ARGS > $OUT/a.log 2>&1
