@@ -61,6 +61,27 @@ class StemArgs(C.Structure):
                 ("out", _f), ("out_pool", _f)]
 
 
+class PackSrc(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("stride", C.c_int32), ("c_base", C.c_int32)]
+
+
+class PackBn(C.Structure):
+    _fields_ = [("gamma", _f), ("beta", _f), ("mean", _f), ("var", _f), ("eps", C.c_float)]
+
+
+class PackConvDesc(C.Structure):
+    _fields_ = [("weight", _f), ("bias", _f), ("bn", PackBn),
+                ("cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
+                ("pad", C.c_int32), ("dilation", C.c_int32),
+                ("src", C.POINTER(PackSrc)), ("n_src", C.c_int32),
+                ("proj_weight", _f), ("proj_bias", _f), ("proj_bn", PackBn), ("proj", PackSrc)]
+
+
+class PackInfo(C.Structure):
+    _fields_ = [("n_pad", C.c_int32), ("k_pad", C.c_int32), ("n_slots", C.c_int32), ("patch", C.c_int32),
+                ("out_scale", C.c_float), ("weight_bytes", C.c_size_t)]
+
+
 class DecodeArgs(C.Structure):
     _fields_ = [("scores", _f), ("inds", _f), ("classes", _f), ("reg", _f), ("wh", _f),
                 ("depth", _f), ("rot", _f), ("dim", _f), ("amodal", _f), ("att", _f), ("vel", _f),
@@ -112,6 +133,10 @@ SYMBOLS = {
     "cf_serialize_max_candidates": (_i, []),
     "cf_spin_us": (_i, [_i, _f]),
     "cf_last_error": (C.c_char_p, []),
+    "cf_pack_conv_f16x3_info": (_i, [C.POINTER(PackConvDesc), C.POINTER(PackInfo)]),
+    "cf_pack_conv_f16x3": (_i, [C.POINTER(PackConvDesc), _f, _f, _f, C.POINTER(PackInfo)]),
+    "cf_pack_dcn_f16_info": (_i, [_i, _i, C.POINTER(PackInfo)]),
+    "cf_pack_dcn_f16": (_i, [_f, _f, C.POINTER(PackBn), _i, _i, _f, _f, C.POINTER(PackInfo)]),
     "cf_abi_version": (_i, []),
 }
 

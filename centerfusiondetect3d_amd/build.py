@@ -29,6 +29,7 @@ SOURCES = [
     ("cf_heads.hip", []),
     ("cf_elementwise.hip", []),
     ("cf_post.hip", ["-ffp-contract=off"]),
+    ("cf_pack.cpp", ["-ffp-contract=off"]),     # host-side packers: the fp32 BN fold must round like torch's (no fused multiply-add)
     ("cf_error.cpp", []),
 ]
 

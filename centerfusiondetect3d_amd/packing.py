@@ -26,7 +26,9 @@ def fold_bn(weight, bias, bn):
     if bn is None:
         return w, b
     g, beta, mean, var = (t.detach().float().cpu() for t in bn)
-    scale = g / torch.sqrt(var + BN_EPS)
+    # (the square root through float64: correctly rounded in fp32, which torch's vectorised fp32 sqrt is not for every
+    #  length - the C packer, cf_pack_conv_f16x3 / cf_pack_dcn_f16, uses sqrtf and has to produce the same bytes)
+    scale = g / torch.sqrt((var + BN_EPS).double()).float()
     return w * scale.view(-1, *([1] * (w.dim() - 1))), (b - mean) * scale + beta
 
 

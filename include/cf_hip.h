@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 5 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx, cf_dcn_args.out_mx; 5: cf_conv3x3_proj_f16x3, cf_stem_args.out_pool */
+#define CF_ABI_VERSION 5 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx, cf_dcn_args.out_mx; 5: cf_conv3x3_proj_f16x3, cf_stem_args.out_pool, cf_pack_conv_f16x3, cf_pack_dcn_f16 */
 
 #define CF_OK 0
 #define CF_EINVAL (-22)
@@ -154,6 +154,50 @@ int cf_conv3x3_root_f16x3(const cf_conv_args* conv, const cf_conv_args* root, co
  * cf_conv2d_f16x3 on the same slot table (the same products in the same order; the same bits wherever the patch tiling
  * does not split K over waves - maps of at most 512 pixels with 256+ channels do, as in cf_conv3x3_f16x3). */
 int cf_conv3x3_proj_f16x3(const cf_conv_args* a, const int32_t* src_channels, void* stream);
+
+/* ---- (ABI 5) host-side weight preparation: SURVEY 8(b) "cf_pack_weights" (one-time BN fold + layout) -------------------------
+ * Pure CPU functions (no stream, no device memory): HOST pointers in, HOST buffers out; the caller copies the results to the
+ * device once.  They do what centerfusiondetect3d_amd/packing.py does for the Python host - the same arithmetic operation for
+ * operation, the same bytes (tests/test_cabi.py) - so a host in any language can feed the f16x3 operators.  Reference: the
+ * eval-mode BatchNorm the reference runs as its own op behind every convolution (model/networks/dla.py:29, 36-39, 151-159;
+ * DeformConv: dla.py:399-404) is folded here; the heads / stem / upsample packers stay in packing.py. */
+typedef struct cf_pack_src {
+  int32_t channels;   /* real channels this source contributes to the convolution's Cin                  */
+  int32_t stride;     /* floats per pixel of the NHWC tensor holding it (multiple of 8)                  */
+  int32_t c_base;     /* first channel inside that tensor (multiple of 8)                                */
+} cf_pack_src;
+typedef struct cf_pack_bn {        /* eval-mode BatchNorm to fold (per output channel); gamma == NULL: none */
+  const float* gamma; const float* beta; const float* mean; const float* var;
+  float eps;
+} cf_pack_bn;
+typedef struct cf_pack_conv_desc {
+  const float* weight;             /* (cout, sum of src channels, kh, kw), fp32, host                       */
+  const float* bias;               /* (cout) or NULL                                                        */
+  cf_pack_bn bn;
+  int32_t cout, kh, kw, stride;
+  int32_t pad;                     /* < 0: (kh - 1) / 2 * dilation                                          */
+  int32_t dilation;
+  const cf_pack_src* src; int32_t n_src;
+  const float* proj_weight;        /* optional (cout, proj.channels) 1x1 projection summed into the same    */
+  const float* proj_bias;          /*   accumulators (cf_conv3x3_proj_f16x3), with its own BatchNorm        */
+  cf_pack_bn proj_bn;
+  cf_pack_src proj;
+} cf_pack_conv_desc;
+typedef struct cf_pack_info {
+  int32_t n_pad, k_pad;            /* cf_conv_args.N_pad / K_pad (cf_dcn_args: N_pad; K = 9 * C)            */
+  int32_t n_slots;                 /* entries of the slot table (k_pad / 8); 0 for the DCN                  */
+  int32_t patch;                   /* slice-major 3x3 packing: cf_conv3x3_f16x3 / _root / _proj may run it  */
+  float out_scale;                 /* 2^-(s+4): cf_conv_args.out_scale / cf_dcn_args.out_scale              */
+  size_t weight_bytes;             /* size of the packed weight buffer                                      */
+} cf_pack_info;
+/* sizes first (out_scale is not known before the weights are read: 0 here) ... */
+int cf_pack_conv_f16x3_info(const cf_pack_conv_desc* d, cf_pack_info* info);
+/* ... then the packing: weight_out (weight_bytes), slots_out (n_slots), bias_out (n_pad floats), all host memory */
+int cf_pack_conv_f16x3(const cf_pack_conv_desc* d, void* weight_out, cf_slot* slots_out, float* bias_out, cf_pack_info* info);
+/* DeformConv main weights (cout, cin, 3, 3) -> cf_dcn_v2_f16x3's layout (K order tap-major, fp16 hi / lo fragments) */
+int cf_pack_dcn_f16_info(int32_t cout, int32_t cin, cf_pack_info* info);
+int cf_pack_dcn_f16(const float* weight, const float* bias, const cf_pack_bn* bn, int32_t cout, int32_t cin,
+                    void* weight_out, float* bias_out, cf_pack_info* info);
 
 /* cf_split_bf16: fp32 NHWC [M][in_stride] (C used) -> split-bf16 [M][2][Cs], channels C..Cs-1 zero. */
 int cf_split_bf16(const float* x, void* out, long M, int C, int in_stride, int Cs, void* stream);
@@ -416,10 +460,11 @@ typedef struct cf_serialize_args {
 int cf_serialize_nuscenes(const cf_serialize_args* a, void* stream);
 int cf_serialize_max_candidates(void);
 
-/* Weight packing is host-side Python (centerfusiondetect3d_amd/packing.py), not part of this ABI: it
- * runs once per load_state_dict (BatchNorm fold, slot tables, split hi/lo planes, MFMA fragment order)
- * and the reference's own host side is Python.  The layouts the kernels expect are documented at each
- * argument block above and in DESIGN.md section 3. */
+/* Weight packing runs once per load_state_dict (BatchNorm fold, slot tables, split hi / lo planes, MFMA fragment order).
+ * For the f16x3 convolution and DCN operators it is part of this ABI (cf_pack_conv_f16x3, cf_pack_dcn_f16 above: host-side C,
+ * byte-identical to the Python packers); the heads', the stem's and the upsample's weights are packed by
+ * centerfusiondetect3d_amd/packing.py only (the reference's own host side is Python).  The layouts the kernels expect
+ * are documented at each argument block above and in DESIGN.md section 3. */
 
 /* cf_spin_us: diagnostic - ONE 64-thread workgroup that stays resident for `microseconds` (<= 100000) of the
  * constant 100 MHz clock and then exits.  Two of them on two streams finish in ~1x the time when the streams run
