@@ -1,9 +1,9 @@
 """Dev tool (CPU): gate (a) of the heads' FP6 scheme - the oracle's head chain under each candidate arithmetic (bf16x3; fp16 main
 term + block-scaled FP6 cross terms on the first layer / on every layer / with refined weights) against the float64-anchored
 bounds of tests/test_gpu_model.py.  Raw output of the round: docs/experiments/r5_heads_mx_numerics.txt.
-    python tools/eval_head_mx.py /tmp/e2e_2_448_800.pt [variant names ...]"""
+    python tests/tools/eval_head_mx.py /tmp/e2e_2_448_800.pt [variant names ...]"""
 import sys, time, torch
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 import torch.nn.functional as F
 from oracle import model_ref, mx_emul
 from tests.golden import cases

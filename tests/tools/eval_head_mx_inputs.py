@@ -1,8 +1,8 @@
 """Dev tool (CPU): the oracle's fp32 and float64 forwards of Centerfusion_Middle (tuned weights seed 0, inputs seed 5) at B H W ->
 /tmp/e2e_B_H_W.pt (feature map, fp32 outputs, float64 outputs, frustum map): the inputs of tools/eval_head_mx.py.
-    python tools/eval_head_mx_inputs.py 2 448 800"""
+    python tests/tools/eval_head_mx_inputs.py 2 448 800"""
 import sys, time, torch
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from oracle import model_ref, frustum_ref, mx_emul
 from tests.golden import cases
 torch.set_num_threads(8)

@@ -1,9 +1,9 @@
 """Dev tool (GPU box): the float64-anchored accuracy gate of tests/test_gpu_model.py (RMS error of the HIP path against the
 float64 oracle <= 1.25 x the fp32 oracle's own, worst element <= 2 x + 2e-5) over several weight / input seeds, with the
 heads' first layers on fp16 + FP6 (default) and on bf16x3 (--heads-bf16x3): how much margin the scheme keeps.
-    python tools/eval_mx_gate_gpu.py [n_seeds] [--heads-bf16x3]"""
+    python tests/tools/eval_mx_gate_gpu.py [n_seeds] [--heads-bf16x3]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import model_ref, frustum_ref
 from tests.golden import cases
