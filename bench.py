@@ -572,6 +572,8 @@ def main():
                     help="A/B: the level-2 Tree's max-pool as its own launch instead of a second output of the stem (model.stem_pool)")
     ap.add_argument("--no-heads-lanes", action="store_true",
                     help="A/B: the decoder's NMS + top-k behind the forward on the caller's stream instead of beside the secondary heads (model.heads_lanes = False)")
+    ap.add_argument("--root-fuse-children", action="store_true",
+                    help="A/B: conv2 + Root in one launch also for the Roots that read the Tree's children (model.root_fuse_children)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="experiment (never the default line): consecutive steps alternate over this many caller streams, so the "
                          "heads of step i may run beside the backbone of step i+1 (one plan set per stream)")
@@ -642,6 +644,8 @@ def main():
         model.proj_fuse = False
     if args.no_stem_pool:
         model.stem_pool = False
+    if args.root_fuse_children:
+        model.root_fuse_children = True
     if args.no_heads_lanes:
         model.heads_lanes = False
     model = synthetic_weights(model, seed=0, offset_std=args.offset_std).to(dev).eval()

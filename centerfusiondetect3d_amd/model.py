@@ -353,7 +353,8 @@ class _Plan:
                 x1 = block(p + ".tree1", x, residual, pooled=bottom if proj_fused else None)
                 pc2, pcr = pk[p + ".tree2.conv2"], pk[p + ".root"]
                 if (model.root_fuse and model.conv_patch and pc2.out_scale > 0 and pcr.out_scale > 0
-                        and getattr(pc2, "patch", False) and pc2.stride == 1):
+                        and getattr(pc2, "patch", False) and pc2.stride == 1
+                        and (not children or model.root_fuse_children)):
                     # tree2.conv2 and the Root as ONE step (cf_conv3x3_root_f16x3): x2 is never written where a workgroup
                     # holds every channel of its pixels (64 / 128 / 256 channels: levels 2-4; children are read from HBM
                     # inside the launch); the library runs the two launches for every other shape, bit-identical either way
@@ -836,7 +837,9 @@ class DLASeg(nn.Module):
         self.stem_fused = True   # with conv_f16: base_layer + level0 + level1 in one launch (cf_stem.hip)
         self.stem_pool = True    # ... which also writes the level-2 Tree's max-pool of its output (one launch less per trunk)
         self.conv_patch = True   # 3x3 stride-1 f16x3 convs: LDS patch reuse (cf_conv3x3_f16.hip)
-        self.root_fuse = True    # one-level Trees without children: tree2.conv2 + Root as one step (cf_conv3x3_root_f16x3)
+        self.root_fuse = True    # one-level Trees: tree2.conv2 + Root as one step (cf_conv3x3_root_f16x3) ...
+        self.root_fuse_children = False   # ... also where the Root has further sources (level3.tree2, level4.tree2): same bits, and
+                                          # in the two-stream step the two launches are 0.024 ms faster (round 5, 6 of 6 A/B pairs)
         self.heads_lanes = True  # fused heads: the decoder's NMS + top-k on a side stream beside the frustum path and the secondary
                                  # launch (_Plan heads section), handed to decode.py with the heat map
         self.proj_fuse = True    # the sub-tree that opens a level: `project` of the pooled input as k-steps of tree1.conv2
