@@ -574,6 +574,9 @@ def main():
                     help="A/B: the decoder's NMS + top-k behind the forward on the caller's stream instead of beside the secondary heads (model.heads_lanes = False)")
     ap.add_argument("--root-fuse-children", action="store_true",
                     help="A/B: conv2 + Root in one launch also for the Roots that read the Tree's children (model.root_fuse_children)")
+    ap.add_argument("--lanes-max-frames", type=int, default=None,
+                    help="A/B: model.lanes_max_frames (default 4: a trunk of up to that many 448x800-frame equivalents issues its IDA "
+                         "projections on a side stream beside the node chain)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="experiment (never the default line): consecutive steps alternate over this many caller streams, so the "
                          "heads of step i may run beside the backbone of step i+1 (one plan set per stream)")
@@ -646,6 +649,8 @@ def main():
         model.stem_pool = False
     if args.root_fuse_children:
         model.root_fuse_children = True
+    if args.lanes_max_frames is not None:
+        model.lanes_max_frames = args.lanes_max_frames
     if args.no_heads_lanes:
         model.heads_lanes = False
     model = synthetic_weights(model, seed=0, offset_std=args.offset_std).to(dev).eval()
