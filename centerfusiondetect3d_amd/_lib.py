@@ -6,7 +6,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcfhip.so")
 
-ABI_VERSION = 5      # CF_ABI_VERSION of include/cf_hip.h this binding was written against
+ABI_VERSION = 6      # CF_ABI_VERSION of include/cf_hip.h this binding was written against
 CF_MAX_SRC = 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID_CLAMP, ACT_RAW_AND_SIGDEPTH = 0, 1, 2, 3
 LAYOUT_NHWC, LAYOUT_NCHW, LAYOUT_NHWC_SPLIT_BF16 = 0, 1, 2
@@ -21,7 +21,7 @@ class ConvArgs(C.Structure):
                 ("bias", _f), ("K_pad", C.c_int32), ("N", C.c_int32), ("N_pad", C.c_int32),
                 ("residual", _f), ("res_stride", C.c_int32), ("out", _f), ("out2", _f),
                 ("out_stride", C.c_int32), ("out_layout", C.c_int32), ("act", C.c_int32),
-                ("precise", C.c_int32), ("out_scale", C.c_float)]
+                ("precise", C.c_int32), ("out_scale", C.c_float), ("in_scale", C.c_float)]
 
 
 class DcnArgs(C.Structure):
@@ -30,7 +30,8 @@ class DcnArgs(C.Structure):
                 ("N", C.c_int32), ("N_pad", C.c_int32), ("out", _f), ("out_stride", C.c_int32),
                 ("act", C.c_int32), ("precise", C.c_int32), ("out_scale", C.c_float),
                 ("out_split_bf16", _f), ("split_stride", C.c_int32), ("workspace", _f),
-                ("workspace_bytes", C.c_size_t), ("mask_activated", C.c_int32), ("out_mx", _f)]
+                ("workspace_bytes", C.c_size_t), ("mask_activated", C.c_int32), ("out_mx", _f), ("in_scale", C.c_float),
+                ("mx_scale", C.c_float)]
 
 
 CF_MAX_HEADS = 12
@@ -58,7 +59,7 @@ class StemArgs(C.Structure):
                 ("w_base", _f), ("b_base", _f), ("scale_base", C.c_float),
                 ("w_level0", _f), ("b_level0", _f), ("scale_level0", C.c_float),
                 ("w_level1", _f), ("b_level1", _f), ("scale_level1", C.c_float),
-                ("out", _f), ("out_pool", _f)]
+                ("out", _f), ("out_pool", _f), ("in_scale", C.c_float * 3)]
 
 
 class PackSrc(C.Structure):
@@ -110,6 +111,8 @@ SYMBOLS = {
     "cf_head_tail": (_i, [C.POINTER(HeadTailArgs), _f]),
     "cf_head_fused": (_i, [C.POINTER(HeadFusedArgs), _f]),
     "cf_pack_feat_mx": (_i, [_f, _i, _f, C.c_long, _f]),
+    "cf_pack_feat_mx_scaled": (_i, [_f, _i, _f, C.c_long, C.c_float, _f]),
+    "cf_absmax_f32": (_i, [_f, C.c_long, _i, _i, _f, _f]),
     "cf_dcn_v2_fused": (_i, [C.POINTER(DcnArgs), _f]),
     "cf_dcn_v2_f16x3": (_i, [C.POINTER(DcnArgs), _f]),
     "cf_dcn_v2_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <atomic>
 #include <mutex>
 #include "cf_hip.h"
@@ -67,6 +68,16 @@ __device__ __forceinline__ void cf_wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
+}
+
+// Activation pre-scale of the f16x3 / mx kernels as it arrives over the ABI (cf_conv_args.in_scale, ...): 0 = the default 16;
+// anything else has to be a positive, finite power of two (so that scaling and un-scaling are exact).  -> the scale, or 0 if invalid.
+static inline float cf_resolve_in_scale(float s) {
+  if (s == 0.0f) return 16.0f;
+  uint32_t b;
+  memcpy(&b, &s, 4);
+  const uint32_t e = (b >> 23) & 0xff;
+  return ((b >> 31) == 0 && (b & 0x7fffff) == 0 && e > 0 && e < 255) ? s : 0.0f;
 }
 
 __device__ __forceinline__ float cf_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

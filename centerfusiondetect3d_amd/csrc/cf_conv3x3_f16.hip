@@ -68,6 +68,8 @@ struct Conv3F {
   int root_xsrc_c[2], root_xsrc_ch[2];   // floats per pixel, channels (multiples of 64)
   int root_nks;                          // k-steps of the whole Root: (2 N + children's channels) / 16
   float out_scale;
+  float in_scale;        // activation pre-scale of this convolution's operands (patch rows, projected rows)
+  float root_in_scale;   // ROOT only: ... and of the Root GEMM's operands (x2, x1, the children)
   // PROJ only: a 1x1 convolution of a second tensor (same map as the output) summed into the same accumulators
   const float* proj_x;
   int proj_c, proj_ch, proj_nks, proj_ks0;   // floats per pixel, channels (multiple of 32), k-steps, first k-step in the stream
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
       const int u = tid_s + NT * it;
       const int row = u / UPR, q = u % UPR;
       if (row < p.PR) {
-        const f32x4 xs = goff[it] >= 0 ? raw[it] * ASCALE : f32x4{0.f, 0.f, 0.f, 0.f};   // (a select: the dummy read may hold anything)
+        const f32x4 xs = goff[it] >= 0 ? raw[it] * p.in_scale : f32x4{0.f, 0.f, 0.f, 0.f};   // (a select: the dummy read may hold anything)
         uint2 hi2, lo2;
         split2(xs[0], xs[1], hi2.x, lo2.x);
         split2(xs[2], xs[3], hi2.y, lo2.y);
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const f32x4 xs = xv[j] * ASCALE;
+              const f32x4 xs = xv[j] * p.in_scale;
               uint2 hi2, lo2;
               split2(xs[0], xs[1], hi2.x, lo2.x);
               split2(xs[2], xs[3], hi2.y, lo2.y);
@@ -501,7 +503,7 @@ __global__ __launch_bounds__(64 * WC * WP * WK, MINB) void conv3x3_f16x3_kernel(
       return m < p.M;
     };
     auto put_split = [&](unsigned char* reg, int ploc, const f32x4& v) {   // 4 channels of one pixel -> B tile (hi, lo)
-      const f32x4 xs = v * ASCALE;
+      const f32x4 xs = v * p.root_in_scale;
       uint2 hi2, lo2;
       split2(xs[0], xs[1], hi2.x, lo2.x);
       split2(xs[2], xs[3], hi2.y, lo2.y);
@@ -874,6 +876,8 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const i
   k.n_rt = a->N_pad / 32; k.n_ks = a->K_pad / 16;
   k.res_stride = a->res_stride; k.out_stride = a->out_stride; k.act = a->act;
   k.out_scale = a->out_scale;
+  k.in_scale = cf_resolve_in_scale(a->in_scale);
+  CF_REQUIRE(k.in_scale > 0.0f, "cf_conv3x3_f16x3: in_scale must be 0 (= 16) or a power of two");
   if (proj_ch) {
     k.proj_x = a->src[1];
     k.proj_c = a->src_c[1];
@@ -897,6 +901,8 @@ static int conv3x3_impl(const cf_conv_args* a, const cf_conv_args* root, const i
     kr.root_out_stride = root->out_stride;
     kr.root_act = root->act;
     kr.root_scale = root->out_scale;
+    kr.root_in_scale = cf_resolve_in_scale(root->in_scale);
+    CF_REQUIRE(kr.root_in_scale > 0.0f, "cf_conv3x3_root_f16x3: the Root's in_scale must be 0 (= 16) or a power of two");
     kr.root_nks = root->K_pad / 16;
     for (int i = 0; i < 2; ++i) {
       kr.root_xsrc[i] = i + 2 < root->n_src ? root->src[i + 2] : nullptr;

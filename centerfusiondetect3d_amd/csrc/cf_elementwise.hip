@@ -188,6 +188,31 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 
 // One workgroup that keeps its CU slot busy for `ticks` of the 100 MHz constant clock (s_memrealtime): the probe
 // host code uses to find out which HIP streams run concurrently (model.py: _side_streams).  Always terminates.
+// max |x| over a strided fp32 matrix, as the BITS of the maximum (non-negative floats order like unsigned integers; a NaN's
+// bits exceed +inf's, so a NaN anywhere comes out as NaN): wave shuffle reduction, one atomicMax per wave.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long M, int C, int stride, unsigned* __restrict__ out) {
+  unsigned best = 0u;
+  const long step = (long)gridDim.x * 256;
+  if (stride == C && (C & 3) == 0) {                       // contiguous rows: 16 bytes per lane
+    const long n4 = M * C / 4;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += step) {
+      const f32x4 v = x4[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) best = max(best, __float_as_uint(v[e]) & 0x7fffffffu);
+    }
+  } else {
+    const long n = M * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += step) {
+      const long m = i / C;
+      best = max(best, __float_as_uint(x[m * stride + (i - m * C)]) & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o, 64));
+  if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
+}
+
 __global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
@@ -265,6 +290,23 @@ extern "C" int cf_nchw_to_nhwc(const float* x, float* out, int B, int C, int H, 
   dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, out, HW, C, out_stride, out_offset);
   return cf_check_launch("cf_nchw_to_nhwc");
+}
+
+extern "C" int cf_absmax_f32(const float* x, long M, int C, int stride, float* out, void* stream) {
+  CF_REQUIRE(x && out, "cf_absmax_f32: null buffer");
+  CF_REQUIRE(M >= 0 && C > 0 && stride >= C, "cf_absmax_f32: bad geometry (M=%ld, C=%d, stride=%d)", M, C, stride);
+  CF_REQUIRE(stride != C || (C & 3) != 0 || (reinterpret_cast<uintptr_t>(x) & 15) == 0, "cf_absmax_f32: contiguous rows must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (const hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st); e != hipSuccess) {
+    cf_set_error("cf_absmax_f32: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return CF_ELAUNCH;
+  }
+  if (M == 0) return CF_OK;
+  const long n = M * C;
+  const long blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, x, M, C, stride,
+                     reinterpret_cast<unsigned*>(out));
+  return cf_check_launch("cf_absmax_f32");
 }
 
 extern "C" int cf_spin_us(int microseconds, void* stream) {

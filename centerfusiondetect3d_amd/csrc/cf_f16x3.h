@@ -8,7 +8,7 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float ASCALE = 16.0f;   // activation pre-scale (2^4), undone by out_scale
+constexpr float ASCALE = 16.0f;   // DEFAULT activation pre-scale (2^4; the kernels take theirs from the argument block: in_scale), undone by out_scale
 constexpr int FROWB = 80;         // LDS bytes per pixel row per plane: 32 f16 + 16 B pad
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -29,9 +29,9 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
   lo = __builtin_bit_cast(unsigned, l);
 }
 
-// 8 fp32 -> scaled, clamped, split into fp16 hi / lo (4 dwords each)
-__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4& hi, u32x4& lo) {
-  const f32x4 a = v0 * ASCALE, b = v1 * ASCALE;
+// 8 fp32 -> scaled by the layer's activation pre-scale, clamped, split into fp16 hi / lo (4 dwords each)
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4& hi, u32x4& lo, float in_scale) {
+  const f32x4 a = v0 * in_scale, b = v1 * in_scale;
   { unsigned th, tl; split2(a[0], a[1], th, tl); hi[0] = th; lo[0] = tl; }
   { unsigned th, tl; split2(a[2], a[3], th, tl); hi[1] = th; lo[1] = tl; }
   { unsigned th, tl; split2(b[0], b[1], th, tl); hi[2] = th; lo[2] = tl; }

@@ -37,6 +37,7 @@ struct ConvF {
   float* out;
   int H, W, Ho, Wo, stride, n_chunks, res_stride, out_stride, act, M, N, HoWo, n_rt;
   float out_scale;
+  float in_scale;               // activation pre-scale (power of two)
 };
 
 // DB: double-buffered pixel tile (one barrier per chunk).  The 256-pixel tile of the 64-channel
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvF p) {
     for (int i = 0; i < WP; ++i) {
       const int pr = tid + 256 * i;
       u32x4 hi, lo;
-      split8(raw[i][0], raw[i][1], hi, lo);
+      split8(raw[i][0], raw[i][1], hi, lo, p.in_scale);
       unsigned char* o = buf + (pr >> 2) * FROWB + (pr & 3) * 16;
       *reinterpret_cast<u32x4*>(o) = hi;
       *reinterpret_cast<u32x4*>(o + PLANE) = lo;
@@ -248,6 +249,8 @@ struct DcnF {
   float* out;
   int om_stride, H, W, C, n_chunks, chunks_per_tap, out_stride, act, M, N, n_rt;
   float out_scale;
+  float in_scale;        // activation pre-scale (power of two), carried by the modulation factor
+  float mx_scale;        // pre-scale of the mx rows (out_mx)
   unsigned* out_split;   // optional split-bf16 copy [M][2][split_stride] (as 32-bit words: 2 bf16 each)
   int split_stride;
   unsigned char* out_mx; // optional mx rows [M][272] (cf_pack_feat_mx's format; N = 64, one 32-channel row tile per wave)
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
 #ifdef CF_DCN_NODESC        // (dev timing experiment: no descriptor phase - every sample is the pixel's own cell with weight 1, 0, 0, 0)
   for (int i = tid; i < PXB * 9; i += 256) {
     const int m = min(m0 + i / 9, p.M - 1);
-    desc[2 * i] = f32x4{__int_as_float(m * p.C), __int_as_float(0), __int_as_float(0), ASCALE};
+    desc[2 * i] = f32x4{__int_as_float(m * p.C), __int_as_float(0), __int_as_float(0), p.in_scale};
     desc[2 * i + 1] = f32x4{1.0f, 0.0f, 0.0f, 0.0f};
   }
   if (false)
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
       dA[0] = __int_as_float(((b * p.H + y0) * p.W + x0) * p.C);
       dA[1] = __int_as_float((max(x1, x0) - x0) * p.C);
       dA[2] = __int_as_float((max(y1, y0) - y0) * p.W * p.C);
-      dA[3] = (p.mask_activated ? omm[it] : cf_sigmoid(omm[it])) * ASCALE;
+      dA[3] = (p.mask_activated ? omm[it] : cf_sigmoid(omm[it])) * p.in_scale;
       dB[0] = (t_ok && l_ok) ? hh * hw : 0.0f;
       dB[1] = (t_ok && r_ok) ? hh * lw : 0.0f;
       dB[2] = (b_ok && l_ok) ? lh * hw : 0.0f;
@@ -701,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void dcn_f16x3_kernel(DcnF p) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[4 * i + e] = p.act == CF_ACT_RELU ? fmaxf(t[e], 0.0f) : t[e];
             }
-            mx_pack_block(v, p.out_mx + m * 272, rt0);
+            mx_pack_block(v, p.out_mx + m * 272, rt0, p.mx_scale);
           }
         }
       }
@@ -827,6 +830,8 @@ extern "C" int cf_conv2d_f16x3(const cf_conv_args* a, void* stream) {
   k.M = (int)M; k.N = a->N; k.HoWo = a->Ho * a->Wo;
   k.n_rt = a->N_pad / 32;
   k.out_scale = a->out_scale;
+  k.in_scale = cf_resolve_in_scale(a->in_scale);
+  CF_REQUIRE(k.in_scale > 0.0f, "cf_conv2d_f16x3: in_scale must be 0 (= 16) or a power of two");
   const size_t dyn = (size_t)k.n_chunks * 4 * sizeof(cf_slot);
   hipStream_t st = (hipStream_t)stream;
   if (a->N_pad == 32) {
@@ -862,6 +867,9 @@ extern "C" int cf_dcn_v2_f16x3(const cf_dcn_args* a, void* stream) {
   k.out_stride = a->out_stride; k.act = a->act; k.M = (int)M; k.N = a->N;
   k.n_rt = a->N_pad / 32;
   k.out_scale = a->out_scale;
+  k.in_scale = cf_resolve_in_scale(a->in_scale);
+  k.mx_scale = cf_resolve_in_scale(a->mx_scale);
+  CF_REQUIRE(k.in_scale > 0.0f && k.mx_scale > 0.0f, "cf_dcn_v2_f16x3: in_scale / mx_scale must be 0 (= 16) or a power of two");
   k.out_split = static_cast<unsigned*>(a->out_split_bf16);
   k.split_stride = a->split_stride;
   k.out_mx = static_cast<unsigned char*>(a->out_mx);

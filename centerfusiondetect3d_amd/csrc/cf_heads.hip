@@ -1309,7 +1309,7 @@ __global__ __launch_bounds__(256, 2) void head_patch16_kernel(HeadPatchK q) {
 // (pixel, 32-channel block); the arithmetic is cf_mx.h: mx_pack_block (shared with the DCN epilogue).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_feat_mx_kernel(const float* __restrict__ x, int in_stride,
-                                                           unsigned char* __restrict__ rows, long M) {
+                                                           unsigned char* __restrict__ rows, long M, float scale) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const long m = t >> 1;
   const int blk = (int)(t & 1);
@@ -1322,19 +1322,25 @@ __global__ __launch_bounds__(256) void pack_feat_mx_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[4 * i + e] = q[e];
   }
-  mx_pack_block(v, rows + m * 272, blk);
+  mx_pack_block(v, rows + m * 272, blk, scale);
 }
 
 }  // namespace
 
-extern "C" int cf_pack_feat_mx(const float* x, int in_stride, void* rows, long M, void* stream) {
+extern "C" int cf_pack_feat_mx_scaled(const float* x, int in_stride, void* rows, long M, float scale, void* stream) {
   CF_REQUIRE(x && rows && M > 0, "cf_pack_feat_mx: null tensor or M=%ld", M);
+  const float sc = cf_resolve_in_scale(scale);
+  CF_REQUIRE(sc > 0.0f, "cf_pack_feat_mx_scaled: scale must be 0 (= 16) or a power of two");
   CF_REQUIRE(in_stride >= 64 && in_stride % 4 == 0, "cf_pack_feat_mx: in_stride=%d (64 channels, 16-byte aligned rows)", in_stride);
   CF_REQUIRE(M < (1L << 30), "cf_pack_feat_mx: M=%ld too large", M);
   const long threads = 2 * M;
   hipLaunchKernelGGL(pack_feat_mx_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     in_stride, static_cast<unsigned char*>(rows), M);
+                     in_stride, static_cast<unsigned char*>(rows), M, sc);
   return cf_check_launch("cf_pack_feat_mx");
+}
+
+extern "C" int cf_pack_feat_mx(const float* x, int in_stride, void* rows, long M, void* stream) {
+  return cf_pack_feat_mx_scaled(x, in_stride, rows, M, 16.0f, stream);
 }
 
 static int fill_tail(const cf_head_tail_args* a, HeadTailK& k, const char* who, bool need_x) {

@@ -1,5 +1,5 @@
 // One 32-channel block of one pixel of the mx feature rows (layout: head_patch16_kernel<.., MX> in cf_heads.hip), shared by
-// cf_pack_feat_mx (cf_heads.hip) and the epilogue of cf_dcn_v2_f16x3 (cf_gemm_f16.hip): v = clamp(16 x), hi = fp16(v),
+// cf_pack_feat_mx (cf_heads.hip) and the epilogue of cf_dcn_v2_f16x3 (cf_gemm_f16.hip): v = clamp(scale x) (scale: a power of two, 16 by default), hi = fp16(v),
 // lo = v - hi (exact); block exponent = smallest e with max|.| <= 7.5 * 2^e, from the bits of the maximum (exponent field - 2,
 // + 1 if the mantissa exceeds 1.875); fields by v_cvt_scalef32_pk32_fp6_f16 / v_cvt_scalef32_2xpk16_fp6_f32 (value / scale, RNE,
 // saturating; field j = channel j).
@@ -16,17 +16,17 @@ typedef unsigned int mxu32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int mx_block_exp(float amax) {   // amax >= 0
   const int bits = __builtin_bit_cast(int, amax);
   const int e = ((bits >> 23) & 0xff) - 127 - 2 + ((bits & 0x7fffff) > 0x700000 ? 1 : 0);
-  return amax == 0.0f ? -127 : e;
+  return e < -127 ? -127 : e;      // (amax = 0, fp32 denormals and maxima below 2^-125: the E8M0 code stays >= 0 - never 255 = NaN)
 }
 
 // x: the 32 channels [32 blk, 32 blk + 32) of one pixel (already activated), row: the pixel's 272-byte row
-__device__ __forceinline__ void mx_pack_block(const float (&x)[32], unsigned char* row, int blk) {
+__device__ __forceinline__ void mx_pack_block(const float (&x)[32], unsigned char* row, int blk, float scale) {
   mxh16x32 h;
   f32x16 le, lo_;                              // lo: even / odd channels (the f32 convert interleaves its two sources)
   float mh = 0.0f, ml = 0.0f;
 #pragma unroll
   for (int j = 0; j < 32; ++j) {
-    const float v = __builtin_amdgcn_fmed3f(x[j] * 16.0f, -65504.0f, 65504.0f);
+    const float v = __builtin_amdgcn_fmed3f(x[j] * scale, -65504.0f, 65504.0f);
     const _Float16 hj = (_Float16)v;
     const float l = v - (float)hj;
     h[j] = hj;
@@ -35,9 +35,9 @@ __device__ __forceinline__ void mx_pack_block(const float (&x)[32], unsigned cha
     ml = fmaxf(ml, fabsf(l));
   }
   const int eh = mx_block_exp(mh), el = mx_block_exp(ml);
-  // (a block of zeros converts with scale 1: 0 / 2^-127 would do as well, this keeps the divide away from the edge)
-  const float sh = mh == 0.0f ? 1.0f : __builtin_bit_cast(float, (eh + 127) << 23);
-  const float sl = ml == 0.0f ? 1.0f : __builtin_bit_cast(float, (el + 127) << 23);
+  // (a block of zeros - or of values below 2^-125, whose exponent is clamped - converts with scale 1: every field is then 0)
+  const float sh = eh <= -127 ? 1.0f : __builtin_bit_cast(float, (eh + 127) << 23);
+  const float sl = el <= -127 ? 1.0f : __builtin_bit_cast(float, (el + 127) << 23);
   // inline asm with an early-clobber destination: hipcc (ROCm 7.2) may allocate the 6-dword result ON TOP of the scale
   // (or a source) register of the builtin form, and the instruction writes its result in passes while still reading them
   // - every field behind the first pair then converts with a clobbered scale (seen: v_cvt_... v[0:5], .., .., v0)

@@ -47,7 +47,8 @@ struct StemK {
   const float* b_base;            // 16
   const float* b_l0;              // 16
   const float* b_l1;              // 32
-  float s_base, s_l0, s_l1;       // 2^-(s+4) per layer
+  float s_base, s_l0, s_l1;       // 2^-s / in_scale per layer
+  float a_img, a_base, a_l0;      // activation pre-scales (in_scale): image, base_layer output, level0 output
   float* out;                     // fp32 NHWC (B, H/2, W/2, 32)
   float* out_pool;                // optional: its 2x2 / stride 2 max-pool, fp32 NHWC (B, H/4, W/4, 32)
   int tiles_x, tiles_y;
@@ -58,8 +59,8 @@ __device__ __forceinline__ const f16x8* sfrag(const unsigned char* w, int idx, i
 }
 
 // 4 fp32 (one pixel, 4 consecutive channels) -> scaled, clamped fp16 hi / lo pairs
-__device__ __forceinline__ void split4(const f32x4v& v, uint2& hi, uint2& lo) {
-  const f32x4v xs = v * ASCALE;
+__device__ __forceinline__ void split4(const f32x4v& v, uint2& hi, uint2& lo, float in_scale) {
+  const f32x4v xs = v * in_scale;
   split2(xs[0], xs[1], hi.x, lo.x);
   split2(xs[2], xs[3], hi.y, lo.y);
 }
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
     for (int it = 0; it < NQ; ++it) {
       const int q = tid + 256 * it;
       uint2 hi, lo;
-      split4(v[it], hi, lo);
+      split4(v[it], hi, lo, p.a_img);
       if (q < ST_RI * ST_RI) *reinterpret_cast<u32x4*>(in_lds + q * 16) = u32x4{hi.x, hi.y, lo.x, lo.y};
     }
   }
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf(acc[u][e] * p.s_base + bias_b[e], 0.0f) : 0.0f;
       uint2 hi, lo;
-      split4(v, hi, lo);
+      split4(v, hi, lo, p.a_base);
       if ((t0 + 4 * u) * 16 + col < NB) {
         *reinterpret_cast<uint2*>(base_lds + q[u] * ST_ROWB + 8 * kg) = hi;
         *reinterpret_cast<uint2*>(base_lds + q[u] * ST_ROWB + 32 + 8 * kg) = lo;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256, 3) void stem_kernel(StemK p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = inside ? fmaxf((accm[u][e] + accs[u][e]) * p.s_l0 + bias_0[e], 0.0f) : 0.0f;
       uint2 hi, lo;
-      split4(v, hi, lo);
+      split4(v, hi, lo, p.a_l0);
       if ((t0 + 4 * u) * 16 + col < N0) {
         *reinterpret_cast<uint2*>(l0_lds + q[u] * ST_ROWB + 8 * kg) = hi;
         *reinterpret_cast<uint2*>(l0_lds + q[u] * ST_ROWB + 32 + 8 * kg) = lo;
@@ -313,6 +314,8 @@ extern "C" int cf_stem_fused(const cf_stem_args* a, void* stream) {
   k.w_l1 = reinterpret_cast<const unsigned char*>(a->w_level1);
   k.b_base = a->b_base; k.b_l0 = a->b_level0; k.b_l1 = a->b_level1;
   k.s_base = a->scale_base; k.s_l0 = a->scale_level0; k.s_l1 = a->scale_level1;
+  k.a_img = cf_resolve_in_scale(a->in_scale[0]); k.a_base = cf_resolve_in_scale(a->in_scale[1]); k.a_l0 = cf_resolve_in_scale(a->in_scale[2]);
+  CF_REQUIRE(k.a_img > 0.f && k.a_base > 0.f && k.a_l0 > 0.f, "cf_stem_fused: in_scale must be 0 (= 16) or a power of two");
   k.out = a->out;
   k.out_pool = a->out_pool;
   k.tiles_x = (a->W / 2 + ST_T1 - 1) / ST_T1;

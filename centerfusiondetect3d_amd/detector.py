@@ -28,13 +28,23 @@ FOCAL_LENGTH = 1200          # datasets/nuscenes.py:34 (used when an image has n
 
 
 class Detector(object):
-    def __init__(self, config, show=False, pause=False, *, model=None, device=None):
+    def __init__(self, config, show=False, pause=False, *, model=None, device=None, range_policy="raise"):
         """detector.py:21-42: `Detector(config, show=False, pause=False)` builds the model with `getModel(config)`
         and, when `config.MODEL.LOAD_DIR` is set (the reference's radar configs set it,
         configs/Centerfusion_Middle.yaml:43), loads that checkpoint with `loadModel` before `.to(device).eval()`.
         A checkpoint that cannot be read raises, as `torch.load` does in the reference: nothing here falls back to
         random weights.  `model=` / `device=` (keyword only, extensions) hand over an already-built module or pick the
-        card.  Visualisation is outside the hot path: `show=True` raises instead of being ignored."""
+        card.  Visualisation is outside the hot path: `show=True` raises instead of being ignored.
+
+        `range_policy` (keyword only, extension): the split-fp16 kernels clamp activations beyond 65504 / pre-scale (4094 at
+        the default pre-scale 16) where the reference's fp32 convolutions accept any magnitude (dla.py:124-159), so the FIRST
+        batch after the weights were loaded goes through the model's range guard: "raise" (default) = `model.check_ranges` -
+        a `CfHipError` naming the layers if any input reaches half that limit, never a silently clamped map; "calibrate" =
+        `model.calibrate` on that batch (per-layer power-of-two pre-scales; results unchanged bit for bit where no layer
+        needs one); "off" = no check.  `model.check_resident_ranges()` re-tests a running service at no extra forward."""
+        if range_policy not in ("raise", "calibrate", "off"):
+            raise ValueError("range_policy must be 'raise', 'calibrate' or 'off'")
+        self.range_policy = range_policy
         if not isinstance(show, bool) or not isinstance(pause, bool):
             raise TypeError("Detector(config, show=False, pause=False, *, model=None, device=None): "
                             "show / pause are booleans; pass a pre-built module as model=")
@@ -102,6 +112,9 @@ class Detector(object):
     def process(self, images, calibs, pc_dep=None, meta=None, mark=None):
         """forward + decode + postProcess -> (outputs, post (B,K,54)).  `mark(name)`: stage-boundary callback (`run` with
         `stage_times`)."""
+        if self.range_policy != "off" and getattr(self.model, "_range_checked", True) is False:
+            # first batch on these weights: the range guard (one slow exact-fp32 forward; sets model._range_checked)
+            (self.model.calibrate if self.range_policy == "calibrate" else self.model.check_ranges)(images, pc_dep, calibs)
         outputs = self.model(images, pc_dep=pc_dep, calib=calibs)
         if mark is not None:
             mark("net")

@@ -264,6 +264,8 @@ class _Plan:
         self.step_index = {}     # conv name -> index in self.steps
         self.step_flops = {}     # conv name -> algorithmic FLOPs of that launch (2*MACs)
         self.timed = {}          # step index -> [(start_event, end_event)] filled while timing is on
+        self.inputs = {}         # layer name -> the resident NHWC tensors that layer's GEMM reads (DLASeg.activation_ranges)
+        self.hidden = set()      # layer names with operands that never reach HBM in this plan (fused intermediates)
         pk = model._packed
         cfg = model.config
         heads, head_conv = dict(cfg.heads), {k: list(v) for k, v in cfg.head_conv.items()}
@@ -289,8 +291,9 @@ class _Plan:
             a = ops.conv_args(pc, srcs, strides or [s.shape[-1] for s in srcs], B, h, w, out,
                               out_stride or pc.n, act, residual,
                               residual.shape[-1] if residual is not None else 0, layout, out2,
-                              out_offset, precise)
+                              out_offset, precise, in_scale=model._scale(name) if pc.out_scale > 0 else None)
             self.keep.append(a)
+            self.inputs[name] = list(srcs)
             self.step_index[name] = len(self.steps)
             self.step_flops[name] = 2.0 * B * ho * wo * pc.n * (pc.kh * pc.kh * sum(
                 int(c) for c in pc.real_cin))
@@ -322,7 +325,8 @@ class _Plan:
                 pc = pk[p + ".conv2"]
                 o = buf(B, ho, wo, pc.n)
                 a = ops.conv_args(pc, [t, pooled], [t.shape[-1], pooled.shape[-1]], B, ho, wo, o, pc.n, ACT_RELU, None, 0,
-                                  LAYOUT_NHWC, None, 0, False)
+                                  LAYOUT_NHWC, None, 0, False, in_scale=model._scale(p + ".conv2"))   # (one pre-scale for both parts)
+                self.inputs[p + ".conv2"], self.inputs[p[:-len(".tree1")] + ".project"] = [t], [pooled]
                 ch = (C.c_int32 * 2)(*[int(c) for c in pc.real_cin])
                 self.keep += [a, ch]
                 name = p + ".conv2+project"
@@ -362,10 +366,12 @@ class _Plan:
                     t, _ = conv(p + ".tree2.conv1", [x1], h, w)
                     x2, o = buf(B, h, w, pc2.n), buf(B, h, w, pcr.n)
                     a2 = ops.conv_args(pc2, [t], [t.shape[-1]], B, h, w, x2, pc2.n, ACT_RELU, x1, x1.shape[-1],
-                                       LAYOUT_NHWC, None, 0, False)
+                                       LAYOUT_NHWC, None, 0, False, in_scale=model._scale(p + ".tree2.conv2"))
                     rsrcs = [x2, x1, *children]
                     ar = ops.conv_args(pcr, rsrcs, [s_.shape[-1] for s_ in rsrcs], B, h, w, o, pcr.n, ACT_RELU, None, 0,
-                                       LAYOUT_NHWC, None, 0, False)
+                                       LAYOUT_NHWC, None, 0, False, in_scale=model._scale(p + ".root"))
+                    self.inputs[p + ".tree2.conv2"], self.inputs[p + ".root"] = [t], [x1, *children]
+                    self.hidden.add(p + ".root")             # (x2 stays on the chip)
                     rch = (C.c_int32 * len(rsrcs))(*[int(c) for c in pcr.real_cin])
                     self.keep += [a2, ar, rch]
                     name = p + ".tree2.conv2+root"
@@ -392,8 +398,10 @@ class _Plan:
             if pd.out_scale > 0:
                 nbytes = self.lib.cf_dcn_v2_workspace_bytes(B, h, w, pd.c, pd.n_pad)
                 ws = buf(nbytes, dtype=torch.uint8) if nbytes else None
-            a = ops.dcn_args(pd, x, om, 32, B, h, w, o, pd.n, ACT_RELU, precise=model.precise, workspace=ws)
+            a = ops.dcn_args(pd, x, om, 32, B, h, w, o, pd.n, ACT_RELU, precise=model.precise, workspace=ws,
+                             in_scale=model._scale(p) if pd.out_scale > 0 else None)
             self.keep.append(a)
+            self.inputs[p] = [x]
             self.step_index[p] = len(self.steps)
             self.step_flops[p] = 2.0 * B * h * w * pd.n * 9 * pd.c
             self.add_step((self.lib.cf_dcn_v2_f16x3 if pd.out_scale > 0 else self.lib.cf_dcn_v2_fused, C.byref(a)))
@@ -446,8 +454,11 @@ class _Plan:
                 y1p = buf(B, H // 4, W // 4, 32) if model.stem_pool else None
                 if y1p is not None:
                     pooled[y1.data_ptr()] = y1p
-                self.stem = ops.stem_args(pk["base.stem"], None, y1, shape=(B, 3, H, W), out_pool=y1p)
+                stem_layers = ("base.base_layer", "base.level0", "base.level1")
+                self.stem = ops.stem_args(pk["base.stem"], None, y1, shape=(B, 3, H, W), out_pool=y1p,
+                                          in_scales=[model._scale(n) for n in stem_layers])
                 self.keep.append(self.stem)
+                self.hidden.update(stem_layers)              # (the image is the caller's, the two maps stay in LDS)
                 self.step_index["base.stem"] = self.in_step
                 self.step_flops["base.stem"] = 2.0 * B * H * W * (16 * 147 + 16 * 144 + 32 * 144 / 4)
             else:
@@ -482,10 +493,12 @@ class _Plan:
                             and a.out_scale > 0 and a.N == 64 and a.N_pad == 64]
                 if producer and bool(model.pack_mx_fused):
                     producer[-1].out_mx = feat_in.data_ptr()
+                    producer[-1].mx_scale = model._feat_scale
                     producer[-1].workspace = None          # (the mx output and a K-split reduction exclude each other)
                 else:
                     self.step_index["feat.pack_mx"] = len(self.steps)
-                    self.add_step((self.lib.cf_pack_feat_mx, feat.data_ptr(), 64, feat_in.data_ptr(), C.c_long(B * h4 * w4)))
+                    self.add_step((self.lib.cf_pack_feat_mx_scaled, feat.data_ptr(), 64, feat_in.data_ptr(), C.c_long(B * h4 * w4),
+                                   C.c_float(model._feat_scale)))
             elif bf:
                 # the split-bf16 copy of the feature map the heads read is written by the epilogue of the DCN
                 # that produces it (f16x3 kernel); a separate split pass only if that kernel is not in use
@@ -512,6 +525,10 @@ class _Plan:
         self.primary = primary
         self.radar = radar
         M4 = B * h4 * w4
+        if feat is not None:                                # the fp32 feature map both head groups read (as mx / split-bf16 / fp32)
+            self.inputs["heads.primary.0"] = [feat]
+            if radar:
+                self.inputs["heads.secondary.0"] = [feat]
 
         def hconv(name, srcs, strides, out_c=None, out=None, out_offset=0, act=ACT_RELU):
             """One hidden head layer: fp32 NHWC or split-bf16 NHWC, depending on model.heads_bf16."""
@@ -856,10 +873,22 @@ class DLASeg(nn.Module):
                                    # (cf_dcn_args.out_mx); False: a separate cf_pack_feat_mx pass (A/B, byte-identical)
         self.record_spans = False  # dev / tests: keep HIP events around each trunk of _forward_concurrent (trunk_overlap)
         self.trunk_spans = []
-        self.register_load_state_dict_post_hook(lambda m, _k: m.invalidate())
+        # Dynamic range of the split-fp16 operands: every activation is multiplied by a per-layer power of
+        # two before it is split into fp16 hi + lo - 16 unless `calibrate` has measured that a layer's inputs need less.
+        self._ranges = None        # {layer name: max |input| measured by calibrate()}; None = the default pre-scale everywhere
+        self._feat_scale = ops.DEFAULT_IN_SCALE   # pre-scale of the heads' mx feature rows (set by _prepare from _ranges)
+        self.range_headroom = 8.0  # a calibrated layer keeps max |input| * scale <= 65504 / this
+        self._range_checked = False  # a check_ranges / calibrate has run on these weights (Detector's first-batch guard)
+        self.register_load_state_dict_post_hook(lambda m, _k: m._weights_changed())
         self.eval()
 
-    # weights changed (load_state_dict / .to()) -> re-pack lazily
+    def _weights_changed(self):
+        """load_state_dict: new weights - re-pack lazily, and whatever was known about the activation ranges is void."""
+        self._ranges = None
+        self._range_checked = False
+        self.invalidate()
+
+    # weights changed or moved (load_state_dict / .to()) -> re-pack lazily
     def invalidate(self):
         self._packed = None
         self._plans = {}
@@ -1028,9 +1057,12 @@ class DLASeg(nn.Module):
                             b_out=b32.to(device), n_out=n_out, mfma16=m16)
             mx = m16 and bool(self.heads_mx)
             self._mx_active = mx
+            # the mx rows' pre-scale: one for both head groups (they read the same rows)
+            fr = [self._ranges[n] for n in ("heads.primary.0", "heads.secondary.0") if self._ranges and n in self._ranges]
+            self._feat_scale = ops.in_scale_for(max(fr), self.range_headroom) if (mx and fr) else ops.DEFAULT_IN_SCALE
             def first(h, srcs):
                 if mx:
-                    d = packing.pack_head_first_mx(hw(h, 0), hb(h, 0), pc=len(srcs) == 2)
+                    d = packing.pack_head_first_mx(hw(h, 0), hb(h, 0), pc=len(srcs) == 2, feat_scale=self._feat_scale)
                     return dict(w_first=d["w_first"].to(device), b_first=d["b_first"].to(device), first_scale=d["first_scale"],
                                 real_cin=d["real_cin"])
                 pc = packing.pack_conv_bf16(hw(h, 0), hb(h, 0), srcs, fragments=16 if m16 else True).to(device)
@@ -1041,6 +1073,168 @@ class DLASeg(nn.Module):
                 pk["tails.secondary"] = {h: dict(tail(h, [2, 4], 6), **first(h, [feat_src, pc_src]))
                                          for h in SECONDARY_HEADS}
         self._packed = pk
+
+    # ----------------------------------------------------------------------------- dynamic range
+    def _range_groups(self):
+        """{layer name: the layer names that share ONE activation pre-scale with it} for every layer of the packed model whose
+        operands are split to fp16 (f16x3 convolutions / DCNs, the fused stem, the heads' mx first layers).  Names are the
+        unfused plan's: `X.tree1.conv2` with its Tree's `X.project` when the projection rides in conv2's accumulators."""
+        pk = self._packed
+        groups = {}
+        for name, pc in pk.items():
+            if isinstance(pc, (dict, tuple)) or getattr(pc, "out_scale", 0.0) <= 0 or name == "base.stem":
+                continue
+            g = self._group_of(name)
+            for n in g:
+                groups[n] = g
+        if "base.stem" in pk:
+            for n in ("base.base_layer", "base.level0", "base.level1"):
+                groups[n] = (n,)
+        if self._mx_active:
+            g = ("heads.primary.0",) + (("heads.secondary.0",) if "tails.secondary" in pk else ())
+            for n in g:
+                groups[n] = g
+        return groups
+
+    def _group_of(self, name):
+        """(name,) or, where a Tree's `project` rides in its tree1.conv2's accumulators, that pair: one pre-scale for both."""
+        pk = self._packed or {}
+        if name.endswith(".project"):
+            c2 = name[:-len(".project")] + ".tree1.conv2"
+            if getattr(pk.get(c2), "proj_k", 0) > 0:
+                return (c2, name)
+        if getattr(pk.get(name), "proj_k", 0) > 0:
+            return (name, name[:-len(".tree1.conv2")] + ".project")
+        return (name,)
+
+    def _scale(self, name):
+        """The activation pre-scale of layer `name` under the current calibration (None = the kernels' default, 16)."""
+        if self._ranges is None:
+            return None
+        vals = [self._ranges[n] for n in self._group_of(name) if n in self._ranges]
+        return ops.in_scale_for(max(vals), self.range_headroom) if vals else None
+
+    def activation_ranges(self):
+        """{layer name: max |x| over the layer's input tensors} read from the RESIDENT buffers of the live plans, i.e. for
+        the most recent forward of each plan: one reduction launch per buffer on the current stream, one device -> host
+        copy - off the hot path, no re-run.  Covers every operand that exists in HBM; the operands fused launches keep on
+        the chip (the stem's two full-resolution maps, x2 of a conv2 + Root launch) are not seen - `hidden_layers()` names
+        them, `measure_ranges` sees them too.  NaN / inf inputs come out as nan / inf."""
+        items = [(name, t) for plan in self._all_plans() for name, ts in plan.inputs.items() for t in ts]
+        if not items:
+            return {}
+        lib, st = _lib.load(), _lib.stream_ptr()
+        dev = items[0][1].device
+        with torch.cuda.device(dev):
+            out = torch.zeros(len(items), device=dev, dtype=torch.float32)
+            for i, (_, t) in enumerate(items):
+                c = t.shape[-1]
+                _lib.check(lib.cf_absmax_f32(t.data_ptr(), t.numel() // c, c, c, out.data_ptr() + 4 * i, st), "cf_absmax_f32")
+            vals = out.cpu().tolist()
+        r = {}
+        for (name, _), v in zip(items, vals):
+            old = r.get(name, 0.0)
+            r[name] = old if old != old else (v if v != v else max(old, v))      # (a NaN sticks)
+        return r
+
+    def hidden_layers(self):
+        """Layer names with operands `activation_ranges` cannot see in the live plans (kept in LDS / registers by a fused launch)."""
+        return sorted(set().union(*[p.hidden for p in self._all_plans()])) if self._all_plans() else []
+
+    def measure_ranges(self, images, pc_dep=None, calib=None):
+        """{layer name: max |x| over that layer's inputs} for THIS batch, every layer, measured on a shadow of the model
+        that runs the exact-fp32 kernels with nothing fused (every intermediate in HBM, no fp16 split anywhere, so no value
+        measured here can itself be a clamped one).  One slow forward (~30 ms at bs=16) + one reduction per buffer; the
+        shadow's plans are freed on return.  Reference semantics this protects: the fp32 convolutions of
+        model/networks/dla.py:124-159 accept any magnitude."""
+        if not images.is_cuda:
+            raise _lib.CfHipError("measure_ranges needs device tensors: the HIP path has no CPU fallback")
+        with self._lock, torch.cuda.device(images.device), torch.no_grad():
+            with torch.random.fork_rng(devices=[]):            # (the shadow's throw-away initialisation draws random numbers)
+                shadow = DLASeg(34, 3, self.config)
+            shadow.load_state_dict(self.state_dict())
+            shadow.to(images.device)
+            shadow.conv_f16, shadow.heads_bf16, shadow.streams, shadow.lanes, shadow.use_graph = False, False, 1, False, False
+            shadow(images, pc_dep=pc_dep, calib=calib)
+            r = shadow.activation_ranges()
+            del shadow
+        return r
+
+    def range_violations(self, ranges, fraction=0.5):
+        """[(layer, max |input|, pre-scale)] for every fp16-split layer whose inputs, under the CURRENT pre-scales, reach
+        `fraction` of the fp16 limit (65504) or are not finite.  ranges: from measure_ranges / activation_ranges."""
+        if self._packed is None:
+            raise _lib.CfHipError("range_violations: run a forward (or check_ranges) first - the weights are not packed yet")
+        out = []
+        for name, g in sorted(self._range_groups().items()):
+            vals = [ranges[n] for n in g if n in ranges]
+            if not vals:
+                continue
+            m = float("nan") if any(v != v for v in vals) else max(vals)
+            s = (self._feat_scale if name.startswith("heads.") else self._scale(name)) or ops.DEFAULT_IN_SCALE
+            if not (m * s < fraction * ops.F16_MAX):
+                out.append((name, m, s))
+        return out
+
+    def _raise_on(self, viol, how):
+        if viol:
+            worst = ", ".join(f"{n}: max |input| {m:.4g} x pre-scale {s:g}" for n, m, s in viol[:6])
+            raise _lib.CfHipError(
+                f"activation range guard ({how}): {len(viol)} layer(s) would be clamped at +-65504 / pre-scale by the split-fp16 "
+                f"kernels ({worst}{', ...' if len(viol) > 6 else ''}).  Call model.calibrate(images, pc_dep=..., calib=...) "
+                "on representative batches (per-layer power-of-two pre-scales), or Detector(..., range_policy='calibrate').")
+
+    def check_ranges(self, images, pc_dep=None, calib=None):
+        """Range guard: measure this batch's activation ranges (`measure_ranges`) and raise `CfHipError` naming every layer
+        whose inputs reach HALF the fp16 limit under the current pre-scales - 65504 / 16 / 2 = 2047 on an uncalibrated
+        model - instead of ever returning a silently clamped map.  -> the ranges."""
+        r = self.measure_ranges(images, pc_dep, calib)
+        with self._lock, torch.cuda.device(images.device):
+            if self._packed is None:
+                self._prepare(images.device)
+            self._raise_on(self.range_violations(r), "check_ranges")
+        self._range_checked = True
+        return r
+
+    def check_resident_ranges(self):
+        """The cheap form of the guard for a running service: the same test on `activation_ranges()` - the buffers the last
+        forwards left in HBM - without a second forward.  Blind to `hidden_layers()`."""
+        r = self.activation_ranges()
+        self._raise_on(self.range_violations(r), "check_resident_ranges")
+        return r
+
+    def calibrate(self, images, pc_dep=None, calib=None, reset=True):
+        """Choose the per-layer activation pre-scales from this batch (accumulating over calls with reset=False): layers whose
+        inputs stay below 1023 keep the default 16 (bit-identical results), the others get the largest power of two with
+        max |input| * scale <= 65504 / range_headroom.  Plans and packed weights are rebuilt lazily.  -> the ranges."""
+        r = self.measure_ranges(images, pc_dep, calib)
+        bad = [n for n, v in r.items() if v != v or v == float("inf")]
+        if bad:
+            raise _lib.CfHipError(f"calibrate: non-finite activations in the inputs of {bad[:6]}")
+        if not reset and self._ranges:
+            r = {k: max(r.get(k, 0.0), self._ranges.get(k, 0.0)) for k in set(r) | set(self._ranges)}
+        with self._lock:
+            self._ranges = r
+            self.invalidate()
+        self._range_checked = True
+        return r
+
+    def calibration(self):
+        """The ranges `calibrate` holds (None if uncalibrated) - save them beside a checkpoint, restore with `set_calibration`."""
+        return None if self._ranges is None else dict(self._ranges)
+
+    def set_calibration(self, ranges):
+        with self._lock:
+            self._ranges = None if ranges is None else {str(k): float(v) for k, v in ranges.items()}
+            self.invalidate()
+        self._range_checked = ranges is not None
+
+    def activation_scales(self):
+        """{layer: pre-scale} of every fp16-split layer under the current calibration (after the weights were packed)."""
+        if self._packed is None:
+            return {}
+        return {n: ((self._feat_scale if n.startswith("heads.") else self._scale(n)) or ops.DEFAULT_IN_SCALE)
+                for n in self._range_groups()}
 
     # ----------------------------------------------------------------------------------- forward
     def forward(self, x, pc_hm=None, pc_dep=None, calib=None):

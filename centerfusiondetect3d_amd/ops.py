@@ -21,10 +21,27 @@ def _need_cuda(*ts):
             raise _lib.CfHipError("libcfhip operators need device tensors (no CPU path)")
 
 
+DEFAULT_IN_SCALE = 16.0     # activation pre-scale of the f16x3 / mx kernels (cf_f16x3.h: ASCALE); 65504 / 16 = 4094 is where they clamp
+F16_MAX = 65504.0
+
+
+def in_scale_for(absmax, headroom=8.0):
+    """The activation pre-scale (a power of two) for a layer whose inputs reach `absmax`: the default 16 while that leaves a
+    factor 4 to the fp16 limit, otherwise the largest power of two that keeps absmax * scale <= 65504 / headroom."""
+    a = float(absmax)
+    if not (a == a) or a == float("inf"):
+        raise _lib.CfHipError("activation range is not finite (NaN / inf in a layer input)")
+    if a * DEFAULT_IN_SCALE <= F16_MAX / 4.0:
+        return DEFAULT_IN_SCALE
+    import math
+    return 2.0 ** math.floor(math.log2(F16_MAX / headroom / a))
+
+
 def conv_args(pc: PackedConv, srcs: Sequence[torch.Tensor], src_strides: Sequence[int], B, H, W,
               out: torch.Tensor, out_stride: int, act=ACT_NONE, residual=None, res_stride=0,
-              layout=LAYOUT_NHWC, out2=None, out_offset=0, precise=True, elem_bytes=4) -> _lib.ConvArgs:
-    """Build (and return for reuse) the argument block of one fused convolution."""
+              layout=LAYOUT_NHWC, out2=None, out_offset=0, precise=True, elem_bytes=4, in_scale=None) -> _lib.ConvArgs:
+    """Build (and return for reuse) the argument block of one fused convolution.  in_scale (f16x3 kernels): the layer's
+    activation pre-scale, a power of two (None = the default 16); out_scale follows it."""
     a = _lib.ConvArgs()
     for i, (s, c) in enumerate(zip(srcs, src_strides)):
         a.src[i] = s.data_ptr()
@@ -42,8 +59,34 @@ def conv_args(pc: PackedConv, srcs: Sequence[torch.Tensor], src_strides: Sequenc
     a.out2 = _lib.ptr(out2)
     a.out_stride, a.out_layout, a.act = out_stride, layout, act
     a.precise = int(bool(precise))
-    a.out_scale = float(getattr(pc, "out_scale", 0.0))
+    a.out_scale = float(getattr(pc, "out_scale", 0.0))        # 2^-(s+4): the packer's figure at the default pre-scale
+    if in_scale is not None and float(in_scale) != DEFAULT_IN_SCALE:
+        a.in_scale = float(in_scale)
+        a.out_scale = a.out_scale * DEFAULT_IN_SCALE / float(in_scale)
     return a
+
+
+def absmax(x, out=None):
+    """max |x| of an fp32 device tensor (contiguous, or a 2-D row-strided view) as a 1-element device tensor: NaN if any
+    element is NaN, inf if any is infinite (cf_absmax_f32).  No host sync."""
+    _need_cuda(x)
+    if x.dtype != torch.float32:
+        raise _lib.CfHipError("absmax: float32 only")
+    if x.is_contiguous():
+        M, Cc, stride = x.numel() // max(1, x.shape[-1] if x.dim() else 1), (x.shape[-1] if x.dim() else 1), (x.shape[-1] if x.dim() else 1)
+        if Cc % 4 or x.data_ptr() % 16:
+            M, Cc, stride = 1, x.numel(), x.numel()        # (one long row: the element-wise path)
+    elif x.dim() == 2 and x.stride(1) == 1:
+        M, Cc, stride = x.shape[0], x.shape[1], x.stride(0)
+    else:
+        raise _lib.CfHipError("absmax: contiguous tensor or a row-strided 2-D view")
+    if out is None:
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+    if x.numel() == 0:
+        out.zero_()
+        return out
+    _lib.check(_lib.load().cf_absmax_f32(x.data_ptr(), M, Cc, stride, out.data_ptr(), _lib.stream_ptr()), "cf_absmax_f32")
+    return out
 
 
 def run_conv_f16(a: _lib.ConvArgs, patch=False):
@@ -200,16 +243,16 @@ def head_fused_args(srcs, src_strides, slots, k_pad, B, H, W, heads, layout3x3=N
     return f
 
 
-def pack_feat_mx(feat, out=None):
+def pack_feat_mx(feat, out=None, scale=None):
     """feat (..., C >= 64) fp32 NHWC (the first 64 channels are the feature map) -> (..., 272) uint8 rows for
-    cf_head_fused with mx = 1 (include/cf_hip.h: cf_pack_feat_mx)."""
+    cf_head_fused with mx = 1 (include/cf_hip.h: cf_pack_feat_mx; scale: the rows' power-of-two pre-scale, None = 16)."""
     _need_cuda(feat)
     assert feat.dtype == torch.float32 and feat.is_contiguous() and feat.shape[-1] >= 64
     M = feat.numel() // feat.shape[-1]
     if out is None:
         out = torch.empty(feat.shape[:-1] + (packing_MX_ROW,), device=feat.device, dtype=torch.uint8)
-    _lib.check(_lib.load().cf_pack_feat_mx(feat.data_ptr(), feat.shape[-1], out.data_ptr(), M, _lib.stream_ptr()),
-               "cf_pack_feat_mx")
+    _lib.check(_lib.load().cf_pack_feat_mx_scaled(feat.data_ptr(), feat.shape[-1], out.data_ptr(), M,
+                                                  float(scale or DEFAULT_IN_SCALE), _lib.stream_ptr()), "cf_pack_feat_mx")
     return out
 
 
@@ -222,7 +265,8 @@ def run_head_tail(a):
 
 
 def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act=ACT_RELU,
-             precise=True, out_split=None, workspace=None, out_mx=None):
+             precise=True, out_split=None, workspace=None, out_mx=None, in_scale=None, mx_scale=None):
+    """in_scale: the activation pre-scale of `x` (f16x3 kernel; None = 16); mx_scale: the pre-scale of the out_mx rows."""
     a = _lib.DcnArgs()
     a.x, a.offmask, a.om_stride = x.data_ptr(), offmask.data_ptr(), om_stride
     a.B, a.H, a.W, a.C = B, H, W, pd.c
@@ -230,6 +274,11 @@ def dcn_args(pd: PackedDcn, x, offmask, om_stride, B, H, W, out, out_stride, act
     a.out, a.out_stride, a.act = out.data_ptr(), out_stride, act
     a.precise = int(bool(precise))
     a.out_scale = float(getattr(pd, "out_scale", 0.0))
+    if in_scale is not None and float(in_scale) != DEFAULT_IN_SCALE:
+        a.in_scale = float(in_scale)
+        a.out_scale = a.out_scale * DEFAULT_IN_SCALE / float(in_scale)
+    if mx_scale is not None and float(mx_scale) != DEFAULT_IN_SCALE:
+        a.mx_scale = float(mx_scale)
     if out_split is not None:            # (B,H,W,2,Cs) bf16: split copy for the head kernels (f16x3 kernel only)
         a.out_split_bf16, a.split_stride = out_split.data_ptr(), out_split.shape[-1]
     if out_mx is not None:               # (B,H,W,272) uint8: the mx rows of the heads' first layer (f16x3 kernel, N = 64)
@@ -284,6 +333,21 @@ def set_dcn_pack_verify(on=True):
     loop whose weights are frozen (and call `clear_dcn_pack_cache()` after any manual write).  -> previous setting."""
     global _DCN_PACK_VERIFY
     prev, _DCN_PACK_VERIFY = _DCN_PACK_VERIFY, bool(on)
+    return prev
+
+
+_DCN_RANGE_CHECK = True
+
+
+def set_dcn_range_check(on=True):
+    """`deform_conv2d` evaluates its products from fp16-split operands after a power-of-two pre-scale of the input (16 by
+    default: |input| up to 4094).  With the check ON (the default) every call measures max |input| (cf_absmax_f32, one
+    device->host scalar) and picks the pre-scale for it, so any finite fp32 input is accepted as torchvision's operator
+    accepts it; a NaN / inf input raises.  OFF: the default pre-scale, no sync - inputs beyond 4094 are then CLAMPED silently;
+    only for callers that know their range.  Inside a stream capture the check cannot run (no sync): default pre-scale.
+    -> previous setting."""
+    global _DCN_RANGE_CHECK
+    prev, _DCN_RANGE_CHECK = _DCN_RANGE_CHECK, bool(on)
     return prev
 
 
@@ -402,7 +466,10 @@ def deform_conv2d(input, offset, weight, bias=None, stride=(1, 1), padding=(0, 0
     out = torch.empty((B, H, W, pd.n_pad), device=dev, dtype=torch.float32)     # (any Cout: the row stride is N_pad)
     nbytes = _lib.load().cf_dcn_v2_workspace_bytes(B, H, W, pd.c, pd.n_pad)
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8) if nbytes else None
-    a = dcn_args(pd, x, om, 32, B, H, W, out, pd.n_pad, ACT_NONE, precise=True, workspace=ws)
+    in_scale = None
+    if _DCN_RANGE_CHECK and not torch.cuda.is_current_stream_capturing():
+        in_scale = in_scale_for(float(absmax(x).item()))          # (raises on NaN / inf)
+    a = dcn_args(pd, x, om, 32, B, H, W, out, pd.n_pad, ACT_NONE, precise=True, workspace=ws, in_scale=in_scale)
     a.mask_activated = 1
     run_dcn(a)
     return nhwc_to_nchw(out, channels=pd.n)
@@ -596,9 +663,10 @@ def pillar_expand(pc_2d, pc_3d, counts, calib, trans, out_hw, pillar_dims=(1.5, 
     return (pc_dep, keep, xy) if want_aux else pc_dep
 
 
-def stem_args(ps, x, out, shape=None, out_pool=None) -> _lib.StemArgs:
+def stem_args(ps, x, out, shape=None, out_pool=None, in_scales=None) -> _lib.StemArgs:
     """x may be None with shape=(B, C, H, W) given: the image pointer is then patched in per call.
-    out_pool: optional (B, H/4, W/4, 32) buffer for the 2x2 max-pool of the level1 map."""
+    out_pool: optional (B, H/4, W/4, 32) buffer for the 2x2 max-pool of the level1 map.
+    in_scales: activation pre-scales (powers of two) of the image, base_layer's output, level0's output (None = 16 each)."""
     a = _lib.StemArgs()
     B, Cc, H, W = shape if x is None else x.shape
     a.x, a.B, a.C, a.H, a.W = (_lib.ptr(x), B, Cc, H, W)
@@ -607,6 +675,11 @@ def stem_args(ps, x, out, shape=None, out_pool=None) -> _lib.StemArgs:
     a.w_level1, a.b_level1, a.scale_level1 = ps.w_level1.data_ptr(), ps.b_level1.data_ptr(), ps.scale_level1
     a.out = out.data_ptr()
     a.out_pool = _lib.ptr(out_pool)
+    if in_scales is not None:
+        for i, (s, name) in enumerate(zip(in_scales, ("scale_base", "scale_level0", "scale_level1"))):
+            if s is not None and float(s) != DEFAULT_IN_SCALE:
+                a.in_scale[i] = float(s)
+                setattr(a, name, getattr(a, name) * DEFAULT_IN_SCALE / float(s))
     return a
 
 

@@ -454,16 +454,17 @@ def mx_quant_blocks(v):
     return codes, (e + 127).to(torch.uint8)
 
 
-def pack_head_first_mx(weight, bias, pc: bool):
+def pack_head_first_mx(weight, bias, pc: bool, feat_scale: float = 16.0):
     """First 3x3 layer of one head (256, 64 [+3], 3, 3) -> the operand stream of head_patch16_kernel<..., MX>.
 
-    Returns dict(w_first uint8, b_first f32 (256), first_scale 2^-(s+4), real_cin).  Layout of w_first: for wave wv
+    feat_scale: the power of two the mx feature rows were written with (cf_pack_feat_mx: 16; a calibrated model may use less).
+    Returns dict(w_first uint8, b_first f32 (256), first_scale 2^-s / feat_scale, real_cin).  Layout of w_first: for wave wv
     (64 output channels = 4 row tiles of 16) and tap t a slab of MX_SLAB bytes:
         [rt 4][ks 2][lane 64][8 fp16]   main term: lane (g = l >> 4, i = l & 15) holds Wh[64 wv + 16 rt + i][t, 32 ks + 8 g + j]
         [rt 4]([lane 64][16 B] | [lane 64][8 B])   cross term, 24 B per lane = 32 FP6 fields: g = 0, 1: q6(Wh) channels
                                         32 g .. +32 (to meet q6(xl)); g = 2, 3: q6(Wl) channels 32 (g - 2) .. +32 (to meet q6(xh))
         [lane 64][4 B]                  E8M0 scale bytes of that lane's block, byte rt
-    then (pc only) the pc_hm part as bf16x3 fragments of W * 2^(s+4): [wv 4][ks 3][rt 4][hi, lo][lane 64][8 bf16], k-step ks =
+    then (pc only) the pc_hm part as bf16x3 fragments of W * 2^s * feat_scale: [wv 4][ks 3][rt 4][hi, lo][lane 64][8 bf16], k-step ks =
     taps 4 ks .. 4 ks + 3 x 8 channels (3 real)."""
     co, ci, kh, kw = weight.shape
     assert co == 256 and (kh, kw) == (3, 3) and ci == (67 if pc else 64)
@@ -489,7 +490,7 @@ def pack_head_first_mx(weight, bias, pc: bool):
     parts = [out.reshape(-1)]
     if pc:
         wp = torch.zeros(256, 12, 8, dtype=torch.float64)                               # (row, tap (9 real), 8 ch (3 real))
-        wp[:, :9, :3] = (w[:, 64:67] * 2.0 ** (s_exp + 4)).permute(0, 2, 3, 1).reshape(256, 9, 3)
+        wp[:, :9, :3] = (w[:, 64:67] * 2.0 ** s_exp * float(feat_scale)).permute(0, 2, 3, 1).reshape(256, 9, 3)
         wp = wp.float().view(256, 3, 32)                                                # k-step ks: k = 8 (tap - 4 ks) + c
         ph = wp.to(torch.bfloat16)
         pl = (wp - ph.float()).to(torch.bfloat16)
@@ -497,5 +498,5 @@ def pack_head_first_mx(weight, bias, pc: bool):
         parts.append(f.view(torch.uint8).reshape(-1))
     b = torch.zeros(256)
     b[:co] = bias.float()
-    return dict(w_first=torch.cat(parts).contiguous(), b_first=b, first_scale=2.0 ** -(s_exp + 4),
+    return dict(w_first=torch.cat(parts).contiguous(), b_first=b, first_scale=2.0 ** -s_exp / float(feat_scale),
                 real_cin=(64, 3) if pc else (64,))

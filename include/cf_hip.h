@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 5 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx, cf_dcn_args.out_mx; 5: cf_conv3x3_proj_f16x3, cf_stem_args.out_pool, cf_pack_conv_f16x3, cf_pack_dcn_f16 */
+#define CF_ABI_VERSION 6 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx, cf_dcn_args.out_mx; 5: cf_conv3x3_proj_f16x3, cf_stem_args.out_pool, cf_pack_conv_f16x3, cf_pack_dcn_f16; 6: in_scale (per-layer activation pre-scale of the f16x3 kernels) in cf_conv_args / cf_dcn_args / cf_stem_args, cf_dcn_args.mx_scale, cf_pack_feat_mx_scaled, cf_absmax_f32 */
 
 #define CF_OK 0
 #define CF_EINVAL (-22)
@@ -79,7 +79,12 @@ typedef struct cf_conv_args {
   int32_t out_layout;           /* CF_LAYOUT_*                                                        */
   int32_t act;                  /* CF_ACT_*                                                           */
   int32_t precise;              /* !=0: two-level (per-32-K-chunk) fp32 summation, see cf_gemm.hip    */
-  float out_scale;              /* cf_conv2d_f16x3 only: 2^-(s+4), s = weight scale exponent          */
+  float out_scale;              /* f16x3 kernels only: 2^-s / in_scale, s = weight scale exponent (2^-(s+4) at the
+                                   default in_scale)                                                   */
+  float in_scale;               /* (ABI 6) f16x3 kernels only: the power of two every source value (and, in the fused
+                                   Root / projection forms, every operand of that GEMM) is multiplied by before
+                                   the split into fp16 hi + lo.  0 = the default 16.  |x| * in_scale must stay
+                                   below 65504: larger values are CLAMPED (see "Dynamic range" below)  */
 } cf_conv_args;
 int cf_conv2d_fused(const cf_conv_args* a, void* stream);
 
@@ -98,6 +103,8 @@ typedef struct cf_stem_args {
   float* out;                     /* fp32 NHWC (B, H/2, W/2, 32)                               */
   float* out_pool;                /* (ABI 5) optional: MaxPool2d(2, 2) of `out`, fp32 NHWC (B, H/4, W/4, 32) - the level-2
                                      Tree's downsample (dla.py:96), written from the same registers; NULL = not written */
+  float in_scale[3];              /* (ABI 6) activation pre-scale (power of two, 0 = 16) of the image, of base_layer's output
+                                     and of level0's output; scale_* = 2^-s / in_scale[i] of the layer that reads it */
 } cf_stem_args;
 int cf_stem_fused(const cf_stem_args* a, void* stream);
 
@@ -275,6 +282,9 @@ int cf_head_fused(const cf_head_fused_args* a, void* stream);
  * replaces: nothing in the reference - it is the operand preparation of model/networks/detectHeads.py:64-79 on this path
  * (the fp32 -> split conversion the bf16x3 heads take from cf_split_bf16 / the DCN epilogue).  ABI 4 */
 int cf_pack_feat_mx(const float* x, int in_stride, void* rows, long M, void* stream);
+/* (ABI 6) the same rows with hi = fp16(clamp(scale x)), lo = scale x - hi for a power-of-two `scale` (cf_pack_feat_mx: 16); the
+ * head launch that reads them gets first_scale = 2^-s / scale.  For feature maps whose values exceed 65504 / 16 / 2. */
+int cf_pack_feat_mx_scaled(const float* x, int in_stride, void* rows, long M, float scale, void* stream);
 
 /* cf_dcn_v2_fused: modulated deformable 3x3 convolution (stride 1, pad 1, dil 1, groups 1) with
  * the bilinear gather fused into the GEMM A-tile staging, + bias(BN folded) + ReLU.
@@ -294,7 +304,7 @@ typedef struct cf_dcn_args {
   int32_t out_stride;
   int32_t act;
   int32_t precise;      /* as cf_conv_args.precise              */
-  float out_scale;      /* cf_dcn_v2_f16x3 only: 2^-(s+4)       */
+  float out_scale;      /* cf_dcn_v2_f16x3 only: 2^-s / in_scale (2^-(s+4) at the default in_scale) */
   void* out_split_bf16; /* cf_dcn_v2_f16x3 only, optional: the same result additionally as split-bf16 NHWC
                            [B][H][W][2 (hi, lo)][split_stride] - what the head kernels read (saves cf_split_bf16) */
   int32_t split_stride; /* channels per plane of out_split_bf16 (>= N, multiple of 8) */
@@ -308,6 +318,9 @@ typedef struct cf_dcn_args {
   void* out_mx;           /* cf_dcn_v2_f16x3 only, optional, N = N_pad = 64, not on K-split maps: the same result additionally
                              as the [B*H*W][272] byte rows of cf_pack_feat_mx (bit-identical to packing `out`): the operand
                              format of cf_head_fused with mx = 1 - saves that pass over the feature map.  ABI 4 */
+  float in_scale;         /* (ABI 6) cf_dcn_v2_f16x3 only: power of two the sampled values are multiplied by (through the
+                             modulation factor) before the fp16 split; 0 = 16; as cf_conv_args.in_scale */
+  float mx_scale;         /* (ABI 6) with out_mx: the rows' pre-scale (cf_pack_feat_mx_scaled's `scale`); 0 = 16 */
 } cf_dcn_args;
 int cf_dcn_v2_fused(const cf_dcn_args* a, void* stream);
 
@@ -465,6 +478,19 @@ int cf_serialize_max_candidates(void);
  * byte-identical to the Python packers); the heads', the stem's and the upsample's weights are packed by
  * centerfusiondetect3d_amd/packing.py only (the reference's own host side is Python).  The layouts the kernels expect
  * are documented at each argument block above and in DESIGN.md section 3. */
+
+/* Dynamic range of the f16x3 / mx kernels.  They evaluate fp32 products from operands split into two fp16 values after a
+ * power-of-two pre-scale: weights per layer (chosen by the packer from max|W|), activations by `in_scale` (default 16).  An
+ * activation with |x| * in_scale > 65504 is CLAMPED to +-65504 / in_scale - silently, the kernels carry no overflow flag.
+ * The reference's fp32 convolutions accept any magnitude (model/networks/dla.py:124-159), so a caller must either know
+ * its activations stay below 65504 / in_scale (4094 at the default) or measure them - cf_absmax_f32 on the source buffers -
+ * and pass a smaller in_scale (out_scale = 2^-s / in_scale).  The Python host does exactly that: DLASeg.check_ranges /
+ * calibrate / activation_ranges (centerfusiondetect3d_amd/model.py), Detector(range_policy=...).
+ *
+ * cf_absmax_f32: out[0] = max |x[m][c]| over m < M, c < C of an fp32 buffer with `stride` floats per row, as a float
+ * (NaN if any element is NaN, +inf if any is infinite).  `out` (device, one float) is zeroed by the call (hipMemsetAsync on
+ * `stream`) before the reduction; M = 0 leaves 0 there.  replaces: nothing in the reference (range guard of this path). */
+int cf_absmax_f32(const float* x, long M, int C, int stride, float* out, void* stream);
 
 /* cf_spin_us: diagnostic - ONE 64-thread workgroup that stays resident for `microseconds` (<= 100000) of the
  * constant 100 MHz clock and then exits.  Two of them on two streams finish in ~1x the time when the streams run

@@ -25,11 +25,11 @@ _E2M3 = np.array([(m / 8.0 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 1)) for e 
 
 
 def block_exponent(amax):
-    """numpy float32 array of block maxima -> int32 exponents: smallest e with amax <= 7.5 * 2^e; 0 -> -127."""
+    """numpy float32 array of block maxima -> int32 exponents: smallest e with amax <= 7.5 * 2^e, never below -127; 0 -> -127."""
     a = np.ascontiguousarray(amax, dtype=np.float32)
     bits = a.view(np.int32)
     e = ((bits >> 23) & 0xFF) - 127 - 2 + ((bits & 0x7FFFFF) > 0x700000)
-    return np.where(a == 0, -127, e).astype(np.int32)
+    return np.maximum(np.where(a == 0, -127, e), -127).astype(np.int32)   # (maxima below 2^-125: a zero block, code 0)
 
 
 def e2m3_codes(t):
@@ -55,7 +55,9 @@ def quant_blocks(v):
     b = np.asarray(v, dtype=np.float64).reshape(*v.shape[:-1], v.shape[-1] // 32, 32)
     e = block_exponent(np.abs(b).max(-1).astype(np.float32))
     s = np.ldexp(1.0, e)[..., None]
-    codes = e2m3_codes(b / s)
+    # a block whose exponent sits at the E8M0 floor (max below 1.875 * 2^-125, fp32 denormals included) is a ZERO block: the
+    # pack kernel converts it with scale 1, every field comes out 0 (cf_mx.h)
+    codes = np.where((e <= -127)[..., None], np.uint8(0), e2m3_codes(b / s))
     return codes, e, (e2m3_values(codes) * s).reshape(v.shape)
 
 
@@ -78,9 +80,9 @@ def split_f16(v):
     return hi, v - hi
 
 
-def feat_rows_ref(feat_nhwc):
-    """(M, 64) float32 -> (M, ROW) uint8: what cf_pack_feat_mx writes."""
-    x = np.ascontiguousarray(feat_nhwc, dtype=np.float32) * np.float32(ASCALE)
+def feat_rows_ref(feat_nhwc, scale=ASCALE):
+    """(M, 64) float32 -> (M, ROW) uint8: what cf_pack_feat_mx (scale 16) / cf_pack_feat_mx_scaled write."""
+    x = np.ascontiguousarray(feat_nhwc, dtype=np.float32) * np.float32(scale)
     hi, lo = split_f16(x)
     M = x.shape[0]
     rows = np.zeros((M, ROW), np.uint8)
@@ -129,9 +131,10 @@ def _bf16_split(v):
     return hi, lo
 
 
-def first_layer_mx(feat, pc_hm, weight, bias):
+def first_layer_mx(feat, pc_hm, weight, bias, scale=ASCALE):
     """feat (B,64,H,W) f32, pc_hm (B,3,H,W) f32 or None, weight (Co, 64 [+3], 3, 3), bias (Co) -> (B,Co,H,W) float64:
-    ReLU is NOT applied.  Exact products, float64 accumulation (the MFMA's fp32 accumulation is not modelled)."""
+    ReLU is NOT applied.  Exact products, float64 accumulation (the MFMA's fp32 accumulation is not modelled).
+    scale: the feature map's power-of-two pre-scale (16 unless the model was calibrated for a larger range)."""
     B, C, H, W = feat.shape
     co = weight.shape[0]
     s = weight_scale_exp(weight)
@@ -139,7 +142,7 @@ def first_layer_mx(feat, pc_hm, weight, bias):
     wh, wl = split_f16(wf)
     _, _, wh6 = quant_blocks(wh)
     _, _, wl6 = quant_blocks(wl)
-    cols = F.unfold(feat.float() * ASCALE, 3, padding=1).view(B, C, 9, H * W).permute(0, 2, 1, 3).reshape(B, 9 * 64, H * W)
+    cols = F.unfold(feat.float() * float(scale), 3, padding=1).view(B, C, 9, H * W).permute(0, 2, 1, 3).reshape(B, 9 * 64, H * W)
     out = np.zeros((B, co, H * W))
     for b in range(B):
         x = cols[b].numpy().T                                  # (P, 576), blocks of 32 along k never straddle taps
@@ -150,9 +153,9 @@ def first_layer_mx(feat, pc_hm, weight, bias):
         out[b] = acc
     y = torch.from_numpy(out).view(B, co, H, W)
     if pc_hm is not None:
-        wp = (weight[:, 64:].double() * 2.0 ** (s + 4)).float()
+        wp = (weight[:, 64:].double() * 2.0 ** s * float(scale)).float()
         ph, pl = _bf16_split(wp)
         xh, xl = _bf16_split(pc_hm.float())
         conv = lambda a, w_: F.conv2d(a, w_, None, 1, 1)
         y = y + conv(xh, ph) + conv(xl, ph) + conv(xh, pl)
-    return y * 2.0 ** -(s + 4) + bias.double().view(1, -1, 1, 1)
+    return y * (2.0 ** -s / float(scale)) + bias.double().view(1, -1, 1, 1)

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in cf_hip.h but not exported by libcfhip.so"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes binding"
     assert set(_lib.SYMBOLS) == set(names)
-    assert lib.cf_abi_version() == 5
+    assert lib.cf_abi_version() == 6
     assert lib.cf_topk_workspace_bytes(16, 100) == 16 * 16 * 100 * 8
     assert lib.cf_topk_workspace_bytes_nms(16, 10, 112, 200, 100) == 16 * 16 * 100 * 8 + 16 * 10 * 112 * 200 * 4
 
@@ -51,13 +51,17 @@ def test_struct_layouts_match_c(tmp_path):
                     'printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(cf_stem_args), offsetof(cf_stem_args, out),'
                     'sizeof(cf_head_tail_args), offsetof(cf_head_tail_args, act),'
                     'sizeof(cf_head_fused_args), offsetof(cf_head_fused_args, first_scale),'
-                    'offsetof(cf_dcn_args, workspace), offsetof(cf_dcn_args, out_split_bf16));return 0;}')
+                    'offsetof(cf_dcn_args, workspace), offsetof(cf_dcn_args, out_split_bf16));'
+                    'printf("%zu %zu %zu %zu\\n", offsetof(cf_conv_args, in_scale), offsetof(cf_dcn_args, in_scale),'
+                    'offsetof(cf_dcn_args, mx_scale), offsetof(cf_stem_args, in_scale));return 0;}')
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     assert got == [ctypes.sizeof(_lib.StemArgs), _lib.StemArgs.out.offset,
                    ctypes.sizeof(_lib.HeadTailArgs), _lib.HeadTailArgs.act.offset,
                    ctypes.sizeof(_lib.HeadFusedArgs), _lib.HeadFusedArgs.first_scale.offset,
-                   _lib.DcnArgs.workspace.offset, _lib.DcnArgs.out_split_bf16.offset]
+                   _lib.DcnArgs.workspace.offset, _lib.DcnArgs.out_split_bf16.offset,
+                   _lib.ConvArgs.in_scale.offset, _lib.DcnArgs.in_scale.offset, _lib.DcnArgs.mx_scale.offset,
+                   _lib.StemArgs.in_scale.offset]           # (ABI 6: the activation pre-scales)
 
 
 def test_serialize_struct_layout(tmp_path):

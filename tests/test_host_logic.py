@@ -208,7 +208,7 @@ def test_legacy_keyed_checkpoint_loads(tmp_path):
 
 
 def test_detector_constructor_is_the_references(tmp_path):
-    """detector.py:21: `Detector(config, show=False, pause=False)`; our extensions (`model=`, `device=`) are keyword
+    """detector.py:21: `Detector(config, show=False, pause=False)`; our extensions (`model=`, `device=`, `range_policy=`) are keyword
     only, so a positional `show` can never be taken for a module.  A `MODEL.LOAD_DIR` that names no file raises (the
     reference's `torch.load` would, detector.py:30-31) - before anything touches the GPU, and never silently running
     random-init weights; `show=True` (visualisation, out of scope) raises rather than being ignored."""
@@ -217,7 +217,7 @@ def test_detector_constructor_is_the_references(tmp_path):
     ps = list(inspect.signature(Detector.__init__).parameters.values())
     assert [(p.name, p.default) for p in ps[:4]] == [("self", inspect.Parameter.empty),
                                                       ("config", inspect.Parameter.empty), ("show", False), ("pause", False)]
-    assert all(p.kind is inspect.Parameter.KEYWORD_ONLY for p in ps[4:]) and {p.name for p in ps[4:]} == {"model", "device"}
+    assert all(p.kind is inspect.Parameter.KEYWORD_ONLY for p in ps[4:]) and {p.name for p in ps[4:]} == {"model", "device", "range_policy"}
     cfg = centerfusion_middle_config((64, 64))
     cfg.MODEL.LOAD_DIR = str(tmp_path / "no_such_checkpoint.pth")
     with pytest.raises(FileNotFoundError):

@@ -82,6 +82,10 @@ def epilogue_violations(lines):
             pending = True
         elif re.search(r"s_waitcnt.*lgkmcnt\(0\)", l) or re.search(r"\bs_barrier\b", l):
             pending = False
+        elif re.search(r"\bs_branch\b", l) or "s_endpgm" in l:
+            pending = False                    # (straight-line tracking, as in violations(): the compiler may lay a block of the main
+                                               #  loop - the PROJ staging stores, say - out behind the epilogue marker; its writes end
+                                               #  in a jump back and are not followed by the next block's reads)
         elif pending and re.search(r"\bds_read", l):
             bad.append((i, l.strip()))
             pending = False
