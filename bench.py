@@ -37,6 +37,10 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16 (v_mfma_f32_32x32x16_bf16)
 # dominant kernel = head_patch_kernel (cf_head_fused): its two launches per step (7 primary heads; 4 secondary heads)
 DOMINANT = ["tails.primary", "tails.secondary"]
+# the gather-bound kernel: the 64 -> 64 DeformConv nodes at the H/4 x W/4 maps (dla.py:456-472), and the chip-wide rate at which
+# rows resident in the XCDs' L2s can be gathered (MI355X_MICROARCH.md 'Indexed rows: gather into LDS': 16.8-18.8 TB/s)
+GATHER_LAYERS = ["dla_up.ida_2.node_1", "dla_up.ida_2.node_2", "dla_up.ida_2.node_3", "ida_up.node_1", "ida_up.node_2"]
+L2_GATHER_PEAK_GBS = 18000.0
 # HBM-side bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes over this same command (FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md §HBM); bench.py cannot
 # run the profiler on itself, so the committed measurement is reported.
@@ -352,7 +356,7 @@ def other_configs(dev, steps=12):
                               "per conv-like layer) / time; the counters (`traffic`, `measured_gbs`) see half of that - "
                               "fusion keeps the rest on chip - so the step is NOT HBM-bound at this size: like C2 it is "
                               "bound by MFMA/VALU issue, and `mfma.frac` (x3 for pipe occupancy: 3 passes per MAC) is the "
-                              "figure the counters support.  Kernels at 224x400 maps: profiles/r4_c5_kernel_summary.txt"}
+                              "figure the counters support.  Kernels at 224x400 maps: profiles/r5_c5_kernel_summary.txt"}
     out["C2_exact_fp32"] = measure(16, 448, 800, 0.01, exact_fp32=True, steps=6, warm=2)
     out["C2_single_frame_latency"] = measure(1, 448, 800, 0.01)
     out["C2_one_nuscenes_sample_bs6"] = measure(6, 448, 800, 0.01)     # the 6 cameras of one sample (detector.py:44-155)
@@ -740,6 +744,26 @@ def main():
         model.time_launch(name, False)
         launch_ms += ms
         launch_flops += fl * len(ms)
+    # The kernel furthest below the MFMA roofline, against the roof that does bind it: the 64 -> 64 DCN
+    # layers at the 112 x 200 maps (dcn_f16x3_kernel<2,2,1,true,1>) gather 9 taps x 4 corner rows of C x 4 bytes per output
+    # pixel through the L2 -> TA path.  Timed with HIP events on their launch streams in a few steps BEHIND the timed region
+    # (20 more event pairs per step would sit inside `value` otherwise).
+    gather = None
+    if not args.exact_fp32 and not args.use_graph:
+        with torch.no_grad():
+            for name in GATHER_LAYERS:
+                model.time_launch(name, True)
+            for _ in range(4):
+                step()
+            drain()
+        g_ms, g_bytes = [], 0.0
+        for name in GATHER_LAYERS:
+            ms, fl = model.launch_times(name)
+            model.time_launch(name, False)
+            g_ms += ms
+            g_bytes += fl / (2.0 * 64) * 4 * 4 * len(ms)      # FLOPs = 2 * M * N * 9 * C (N = 64) -> M * 9 * C samples x 4 corners x 4 B
+        if g_ms:
+            gather = (float(np.mean(g_ms)), g_bytes / len(g_ms), len(g_ms))
     assert det.shape == (B * world, 100, 54) and bool(torch.isfinite(det).all())
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -789,6 +813,19 @@ def main():
                          "flop_per_launch": launch_flops, "avg_launch_ms": round(avg_ms, 4),
                          "launches_timed": len(launch_ms)},
         }
+        if gather is not None:
+            g_avg_ms, g_b, g_n = gather
+            gbs = g_b / (g_avg_ms * 1e-3) / 1e9
+            result["roofline_gather"] = {
+                "bound": "l2-gather", "achieved": round(gbs, 1), "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / L2_GATHER_PEAK_GBS, 4),
+                "kernel": "dcn_f16x3_kernel<2,2,1,true,1> (cf_dcn_v2_f16x3: the five 64 -> 64 DeformConv nodes at the H/4 x W/4 maps, "
+                          "one launch per trunk stream and layer)",
+                "note": "corner-row bytes the bilinear gather requests per launch (pixels x 9 taps x 4 corners x 64 channels x 4 B, "
+                        "36 x the unique input) / average launch duration, against the guide's chip-wide L2-resident row-gather rate "
+                        "(16.8-18.8 TB/s, MI355X_MICROARCH.md 'Indexed rows: gather into LDS'); launches of the two trunk streams "
+                        "overlap, so a launch's duration includes what runs beside it; its MFMA-roofline frac is ~0.05",
+                "bytes_per_launch": g_b, "avg_launch_ms": round(g_avg_ms, 4), "launches_timed": g_n}
         default_run = (B, H, W) == (16, 448, 800) and not args.exact_fp32 and args.offset_std == 0.01
         if not args.no_cpu_baseline and world == 1:
             if default_run:

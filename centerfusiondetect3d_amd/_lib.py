@@ -127,7 +127,10 @@ SYMBOLS = {
     "cf_topk_workspace_bytes": (C.c_size_t, [_i, _i]),
     "cf_topk_workspace_bytes_nms": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "cf_topk_peaks": (_i, [_f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f]),
+    "cf_topk_peaks_if_changed": (_i, [_f, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f]),
+    "cf_checksum64": (_i, [_f, C.c_long, _f, _f]),
     "cf_frustum_assoc": (_i, [_f, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, C.c_float, _f, _f, _f, _f]),
+    "cf_topk_frustum": (_i, [_f, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _i, C.c_float, _f, _f, _f, _f, _f, _f, _f, _f]),
     "cf_pillar_expand": (_i, [_f, _f, _f, _i, _i, _i, _f, _f, _i, _i, _d, _d, _d, _f, _f, _f, _f]),
     "cf_decode_gather": (_i, [C.POINTER(DecodeArgs), _f]),
     "cf_post_process": (_i, [_f, _f, _f, _i, _i, _i, _i, _f, _f]),

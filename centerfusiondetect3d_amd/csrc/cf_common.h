@@ -8,6 +8,38 @@
 #include <mutex>
 #include "cf_hip.h"
 
+// Dev timing arms and probes (-DCF_DCN_NOLOAD, -DCF_CONV3_PROF, ...: kernels that skip a part of their work to time the rest -
+// their results are garbage by design - or that write timestamps into their output).  They exist only in builds that ALSO
+// define CF_DEV_ARMS (the tools/ab_*.sh / profile_*.sh scripts do; build.py never does): without it every arm macro is
+// undefined right here, so no stray -D flag can put an arm into the product library, and this list is the complete
+// inventory of what a reader of the kernels may skip.
+#ifndef CF_DEV_ARMS
+#undef CF_CONV3_NOBARRIER
+#undef CF_CONV3_NOPATCH
+#undef CF_CONV3_NOSTAGE
+#undef CF_CONV3_NOWEIGHT
+#undef CF_CONV3_PROF
+#undef CF_CONV3_SHAPE16T
+#undef CF_DCN_DEEP1
+#undef CF_DCN_NOBARRIER
+#undef CF_DCN_NOBLEND
+#undef CF_DCN_NODESC
+#undef CF_DCN_NOEPI
+#undef CF_DCN_NOGATHER
+#undef CF_DCN_NOLOAD
+#undef CF_DCN_NOMFMA
+#undef CF_DCN_NOPIN
+#undef CF_DCN_NOWEIGHT
+#undef CF_DCN_PROF
+#undef CF_DCN_SMALLTILE
+#undef CF_MX_ARM_NOA
+#undef CF_MX_ARM_NOB
+#undef CF_MX_ARM_NOCVT
+#undef CF_MX_ARM_NORED
+#undef CF_NO_WAVE_SYNC
+#undef CF_ONESET
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -68,8 +68,13 @@ __device__ void bitonic_sort_desc(uint64_t* keys, int P) {
 
 // heat * (maxpool3x3(heat) == heat) as its own fully parallel pass (cf_topk_peaks, nms == 2): one
 // thread per element, rows of the 3x3 window served by L1/L2.
+// `only_if` (all three top-k kernels; cf_topk_peaks_if_changed): two 64-bit words in device memory - when they are EQUAL the
+// launch does nothing (the caller's cached result still belongs to the map); nullptr = unconditional.  A uniform scalar test.
+#define CF_SKIP_IF_UNCHANGED(p) if ((p) != nullptr && (p)[0] == (p)[1]) return
+
 __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ heat, float* __restrict__ out, int H,
-                                                  int W, long total) {
+                                                  int W, long total, const unsigned long long* __restrict__ only_if) {
+  CF_SKIP_IF_UNCHANGED(only_if);
   const long N = (long)H * W;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long plane = i / N;
@@ -103,7 +108,9 @@ __device__ __forceinline__ void rank_select_desc(const uint64_t* keys, int n, in
 // 4 x 8-bit radix select and step B is repeated with it.
 template <bool NMS>
 __global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* __restrict__ heat, int C, int H,
-                                                                  int W, int K, uint64_t* __restrict__ out_keys) {
+                                                                  int W, int K, uint64_t* __restrict__ out_keys,
+                                                                  const unsigned long long* __restrict__ only_if) {
+  CF_SKIP_IF_UNCHANGED(only_if);
   __shared__ uint64_t keys[TOPK_CAP];
   __shared__ uint32_t hist[256];
   __shared__ uint32_t wave_cnt[TOPK_THREADS / 64];
@@ -256,36 +263,194 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* _
   for (int j = tid; j < K; j += TOPK_THREADS) out[j] = keys[j];
 }
 
+// Pass 1, register-cached form (maps of up to TOPK_RT * TOPK_RE elements per slice - every map of the 448 x 800 configurations):
+// 1024 threads per slice, each holds its <= 16 elements in registers, so the map is read ONCE with every load of the slice
+// in flight at the same time (the 256-thread kernel above walks the slice twice, four loads per thread at a time: 14 + 14
+// dependent rounds of memory latency per launch - 35 us of the chain between the two head launches).  Same algorithm,
+// same keys: A. lower bound L = the K-th largest of 256 GROUP maxima (a group = 4 neighbouring threads: 256 distinct
+// elements, so at least K elements are >= L); B. everything above L into LDS - from the registers; ties / plateaus and the
+// adversarial case exactly as above, on the registers; C. rank counting.
+constexpr int TOPK_RT = 1024;
+constexpr int TOPK_RE = 16;
+
+__global__ __launch_bounds__(TOPK_RT) void topk_slice_reg_kernel(const float* __restrict__ heat, int C, int H, int W, int K,
+                                                                 uint64_t* __restrict__ out_keys,
+                                                                 const unsigned long long* __restrict__ only_if) {
+  CF_SKIP_IF_UNCHANGED(only_if);
+  __shared__ uint64_t keys[TOPK_CAP];
+  __shared__ uint32_t gmax[256];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t wave_cnt[TOPK_RT / 64];
+  __shared__ uint32_t s_gt, s_sel[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = C * H * W;
+  const int img_i = blockIdx.x / TOPK_SLICES, slice = blockIdx.x % TOPK_SLICES;
+  const float* img = heat + (size_t)img_i * N;
+  const int len = (N + TOPK_SLICES - 1) / TOPK_SLICES;
+  const int lo = min(slice * len, N), hi = min(lo + len, N);
+  uint64_t* out = out_keys + (size_t)blockIdx.x * K;
+  const int n = hi - lo;
+  if (n <= K) {  // tiny slice: everything is a candidate
+    for (int i = tid; i < TOPK_MAXK; i += TOPK_RT)
+      keys[i] = i < n ? (((uint64_t)f2u(img[lo + i]) << 32) | (uint32_t)(~(uint32_t)(lo + i))) : 0ull;
+    __syncthreads();
+    bitonic_sort_desc(keys, TOPK_MAXK);
+    for (int j = tid; j < K; j += TOPK_RT) out[j] = keys[j];
+    return;
+  }
+  // element e of this thread = lo + tid + e * TOPK_RT: for a fixed e the threads walk the slice in index order
+  uint32_t u[TOPK_RE];
+  uint32_t lmax = 0;
+#pragma unroll
+  for (int e = 0; e < TOPK_RE; ++e) {
+    const int i = lo + tid + e * TOPK_RT;
+    u[e] = i < hi ? f2u(img[i]) : 0u;          // (0 ranks below every float but one NaN pattern; validity is tested by index)
+  }
+#pragma unroll
+  for (int e = 0; e < TOPK_RE; ++e) lmax = max(lmax, u[e]);
+  // ---- A: the K-th largest of the 256 group maxima (ties ranked by group id)
+  {
+    uint32_t m = lmax;
+    m = max(m, (uint32_t)__shfl_xor((int)m, 1));
+    m = max(m, (uint32_t)__shfl_xor((int)m, 2));
+    if ((tid & 3) == 0) gmax[tid >> 2] = m;
+  }
+  if (tid == 0) s_sel[0] = 0u;                   // (fewer than K non-empty groups - a slice of < 4 K elements: everything is taken)
+  __syncthreads();
+  if (tid < 256) {
+    const uint32_t mine = gmax[tid];
+    int rank = 0;
+    for (int j = 0; j < 256; ++j) {
+      const uint32_t o = gmax[j];
+      rank += (o > mine || (o == mine && j < tid)) ? 1 : 0;
+    }
+    if (rank == K - 1) s_sel[0] = mine;
+  }
+  __syncthreads();
+  uint32_t L = s_sel[0];
+  __syncthreads();
+
+  // ---- B: collect everything strictly above the bound
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (tid == 0) s_gt = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < TOPK_RE; ++e) {
+      const int i = lo + tid + e * TOPK_RT;
+      if (i < hi && u[e] > L) {
+        const uint32_t pos = atomicAdd(&s_gt, 1u);
+        if (pos < TOPK_CAP) keys[pos] = ((uint64_t)u[e] << 32) | (uint32_t)(~(uint32_t)i);
+      }
+    }
+    __syncthreads();
+    if (s_gt <= TOPK_CAP) break;
+    // exact K-th largest value by radix select (rare path)
+    uint32_t prefix = 0, mask = 0, need = K;
+    for (int pass = 3; pass >= 0; --pass) {
+      const int shift = pass * 8;
+      for (int i = tid; i < 256; i += TOPK_RT) hist[i] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < TOPK_RE; ++e)
+        if (lo + tid + e * TOPK_RT < hi && (u[e] & mask) == prefix) atomicAdd(&hist[(u[e] >> shift) & 255u], 1u);
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t acc = 0;
+        int bin = 255;
+        for (; bin > 0; --bin) {
+          if (acc + hist[bin] >= need) break;
+          acc += hist[bin];
+        }
+        s_sel[0] = (uint32_t)bin;
+        s_sel[1] = need - acc;
+      }
+      __syncthreads();
+      prefix |= s_sel[0] << shift;
+      mask |= 255u << shift;
+      need = s_sel[1];
+      __syncthreads();
+    }
+    L = prefix;  // now fewer than K elements are strictly greater
+  }
+  const int g = (int)s_gt;
+  int total = g;
+  if (g < K) {
+    // index-ordered selection of the (K - g) smallest-index elements equal to L
+    const int r = K - g;
+    int found = 0;
+#pragma unroll 1
+    for (int e = 0; e < TOPK_RE && found < r; ++e) {
+      const int i = lo + tid + e * TOPK_RT;
+      uint32_t ue = 0;
+#pragma unroll
+      for (int q = 0; q < TOPK_RE; ++q) ue = q == e ? u[q] : ue;       // (register array: a select chain, no scratch)
+      const bool eq = i < hi && ue == L;
+      const unsigned long long bal = __ballot(eq);
+      if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(bal);
+      __syncthreads();
+      int wave_off = 0, all = 0;
+      for (int w = 0; w < TOPK_RT / 64; ++w) {
+        const int cw = (int)wave_cnt[w];
+        if (w < wave) wave_off += cw;
+        all += cw;
+      }
+      if (eq) {
+        const int rank = found + wave_off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (rank < r) keys[g + rank] = ((uint64_t)L << 32) | (uint32_t)(~(uint32_t)i);
+      }
+      found += all;
+      __syncthreads();
+    }
+    total = K;
+  }
+  __syncthreads();
+  rank_select_desc(keys, total, K, out);         // (total <= TOPK_CAP = 4 * TOPK_RT)
+}
+
+// Merge of the TOPK_SLICES sorted key lists of one image (keys[] in LDS, list o at keys + o * K; descending, keys unique
+// over the image): best[r] = the key of global rank r < K.  The rank of an element is its position in its own list plus, for
+// every other list, the number of keys above it; that count is found in TWO dependent steps - the list's pivots (every R-th
+// key, R ~ sqrt(K)) and the R keys of the block the pivots point at - with all reads of a step independent of each other
+// (a binary search is 7 dependent LDS round trips per list: the merge took 11.5 us that way).  Whole workgroup; syncs.
+__device__ __forceinline__ void merge_sorted_lists(const uint64_t* keys, int K, uint64_t* __restrict__ best) {
+  const int total = TOPK_SLICES * K;
+  int R = 1;
+  while (R * R < K) ++R;
+  const int n_piv = (K + R - 1) / R;
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
+    const int sl = i / K, pos = i - sl * K;
+    const uint64_t mine = keys[i];
+    int rank = pos;
+    for (int o = 0; o < TOPK_SLICES; ++o) {
+      if (o == sl) continue;
+      const uint64_t* lst = keys + o * K;
+      int c1 = 0;                                  // pivots above mine (monotone: the first c1 of them)
+      for (int j = 0; j < n_piv; ++j) c1 += lst[min((j + 1) * R, K) - 1] > mine ? 1 : 0;
+      const int start = c1 * R;                    // every key before `start` is above mine, the block's pivot (if any) is not
+      int c2 = 0;
+      for (int q = 0; q < R; ++q) c2 += (start + q < K && lst[min(start + q, K - 1)] > mine) ? 1 : 0;
+      rank += start < K ? start + c2 : K;
+      if (rank >= K) break;
+    }
+    if (rank < K) best[rank] = mine;
+  }
+  __syncthreads();
+}
+
 // Pass 2: merge the TOPK_SLICES sorted key lists of one image and emit scores / pixel / class.
 __global__ __launch_bounds__(TOPK_MERGE_THREADS) void topk_merge_kernel(const uint64_t* __restrict__ in_keys,
                                                                         int K, int HW, float* __restrict__ scores,
                                                                         int32_t* __restrict__ inds,
-                                                                        int32_t* __restrict__ classes) {
+                                                                        int32_t* __restrict__ classes,
+                                                                        const unsigned long long* __restrict__ only_if) {
+  CF_SKIP_IF_UNCHANGED(only_if);
   extern __shared__ __attribute__((aligned(16))) uint64_t keys[];      // TOPK_SLICES * K keys
   __shared__ uint64_t best[TOPK_MAXK];
   const int tid = threadIdx.x, total = TOPK_SLICES * K;
   const uint64_t* src = in_keys + (size_t)blockIdx.x * total;
   for (int i = tid; i < total; i += TOPK_MERGE_THREADS) keys[i] = src[i];
   __syncthreads();
-  // every list is sorted (descending, keys unique over the image): the rank of an element is its position in its own
-  // list plus, for every other list, the number of keys above it - a binary search each; ranks below K are the output
-  for (int i = tid; i < total; i += TOPK_MERGE_THREADS) {
-    const int sl = i / K, pos = i - sl * K;
-    const uint64_t mine = keys[i];
-    int rank = pos;
-    for (int o = 0; o < TOPK_SLICES && rank < K; ++o) {
-      if (o == sl) continue;
-      const uint64_t* lst = keys + o * K;
-      int lo = 0, hi = K;                      // first position whose key is NOT above mine
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (lst[mid] > mine) lo = mid + 1; else hi = mid;
-      }
-      rank += lo;
-    }
-    if (rank < K) best[rank] = mine;
-  }
-  __syncthreads();
+  merge_sorted_lists(keys, K, best);
   for (int j = tid; j < K; j += TOPK_MERGE_THREADS) {
     const uint64_t key = best[j];
     const uint32_t idx = ~(uint32_t)key;
@@ -328,12 +493,20 @@ struct FrBox {
   int found;
 };
 
+// slice_keys != nullptr (cf_topk_frustum): the peaks arrive as the TOPK_SLICES sorted key lists of topk_slice_*_kernel and
+// are merged HERE, by every workgroup of the image (3 us of redundant LDS work against a launch + 11 us); workgroup 0 of the
+// image also writes them out as (scores, inds, classes) when asked.  Otherwise `inds` holds the K peaks (cf_frustum_assoc).
 __global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
     const int32_t* __restrict__ inds, int K, const float* __restrict__ depth, const float* __restrict__ wh,
     const float* __restrict__ dim, const float* __restrict__ rot, const float* __restrict__ calib,
     const float* __restrict__ pc_dep, int H, int W, float max_pc_dist, float* __restrict__ pc_hm,
-    float* __restrict__ pc_hm_nhwc4, unsigned* __restrict__ pc_hm_split8) {
+    float* __restrict__ pc_hm_nhwc4, unsigned* __restrict__ pc_hm_split8, const uint64_t* __restrict__ slice_keys,
+    float* __restrict__ tk_scores, int32_t* __restrict__ tk_inds, int32_t* __restrict__ tk_classes) {
   __shared__ FrBox box[FR_MAXK];
+  __shared__ int s_pix[FR_MAXK];               // pixel of peak i
+  __shared__ short cand[FR_MAXK];              // paint: the boxes that touch this workgroup's rows, last painted first
+  __shared__ int s_ncand;
+  extern __shared__ __attribute__((aligned(16))) uint64_t fr_keys[];   // slice_keys: TOPK_SLICES * K keys + K merged
   // FR_SPLIT workgroups per image: each rebuilds the (cheap) box table and paints its share of the
   // pixels - the per-pixel "last covering hit" scan is what takes the time
   const int b = blockIdx.x / FR_SPLIT, part = blockIdx.x % FR_SPLIT;
@@ -346,9 +519,32 @@ __global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
   const float* cal = calib + (size_t)b * 12;
   const float* pc = pc_dep + (size_t)b * 3 * HW;
 
+  if (slice_keys) {
+    const int total = TOPK_SLICES * K;
+    uint64_t* best = fr_keys + total;
+    const uint64_t* src = slice_keys + (size_t)b * total;
+    for (int i = tid; i < total; i += FR_THREADS) fr_keys[i] = src[i];
+    __syncthreads();
+    merge_sorted_lists(fr_keys, K, best);
+    if (tid < K) {
+      const uint64_t key = best[tid];
+      const uint32_t idx = ~(uint32_t)key;
+      const int c = (int)(idx / (uint32_t)HW);
+      s_pix[tid] = (int)(idx - (uint32_t)c * HW);
+      if (part == 0 && tk_inds) {
+        tk_scores[(size_t)b * K + tid] = u2f((uint32_t)(key >> 32));
+        tk_inds[(size_t)b * K + tid] = s_pix[tid];
+        tk_classes[(size_t)b * K + tid] = c;
+      }
+    }
+  } else if (tid < K) {
+    s_pix[tid] = inds[(size_t)b * K + tid];
+  }
+  // (s_pix[tid] is read by the thread that wrote it)
+
   // ---- per-box geometry (utils/pointcloud.py:347-381, 397-437, 468-476)
   if (tid < K) {
-    const int pix = inds[(size_t)b * K + tid];
+    const int pix = s_pix[tid];
     const int yi = pix / W, xi = pix - yi * W;
     const float xs = (float)xi + 0.5f, ys = (float)yi + 0.5f;
     float w = wh_b[pix], h = wh_b[HW + pix];
@@ -398,50 +594,75 @@ __global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
   }
   __syncthreads();
 
-  // ---- nearest gated radar return inside each ROI: one wave per box, row-major first-minimum
+  // ---- nearest gated radar return inside each ROI: one wave per box, row-major first-minimum.  Four positions per lane
+  //      and round in flight; every lane keeps the first minimum of ITS positions (they ascend), the wave then takes the
+  //      smallest value and, among the lanes that hold it, the smallest position: the row-major first occurrence.
   for (int i = wave; i < K; i += FR_THREADS / 64) {
     const FrBox bx = box[i];
     const int rw = bx.roi_x1 - bx.roi_x0, rh = bx.roi_y1 - bx.roi_y0;
     if (rw <= 0 || rh <= 0) continue;
     const int n = rw * rh;
     float best = INFINITY;
-    int best_pos = -1;
-    for (int base = 0; base < n; base += 64) {
-      const int q = base + lane;
-      float dv = INFINITY;
-      if (q < n) {
-        const int yy = bx.roi_y0 + q / rw, xx = bx.roi_x0 + q % rw;
-        const float v = pc[yy * W + xx];
-        if (v != 0.0f && v < bx.hi && v > bx.lo) dv = v;
+    int best_pos = 0x7fffffff;
+    for (int base = 0; base < n; base += 256) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q = base + lane + 64 * j;
+        const int qq = q < n ? q : 0;
+        v[j] = pc[(bx.roi_y0 + qq / rw) * W + bx.roi_x0 + qq % rw];
+        if (q >= n) v[j] = 0.0f;
       }
-      float mn = dv;
-      for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
-      if (mn < best) {  // strict: an earlier chunk keeps ties
-        const unsigned long long bal = __ballot(dv == mn);
-        best = mn;
-        best_pos = base + (int)__ffsll((long long)bal) - 1;
-      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (v[j] != 0.0f && v[j] < bx.hi && v[j] > bx.lo && v[j] < best) {
+          best = v[j];
+          best_pos = base + lane + 64 * j;
+        }
     }
-    if (lane == 0 && best_pos >= 0) {
-      const int yy = bx.roi_y0 + best_pos / rw, xx = bx.roi_x0 + best_pos % rw;
+    float mn = best;
+    for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
+    int pos = (best == mn && mn < INFINITY) ? best_pos : 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) pos = min(pos, __shfl_xor(pos, off));
+    if (lane == 0 && pos != 0x7fffffff) {
+      const int yy = bx.roi_y0 + pos / rw, xx = bx.roi_x0 + pos % rw;
       box[i].found = 1;
-      box[i].val[0] = best / max_pc_dist;
+      box[i].val[0] = mn / max_pc_dist;
       box[i].val[1] = pc[HW + yy * W + xx];
       box[i].val[2] = pc[2 * HW + yy * W + xx];
     }
   }
   __syncthreads();
 
-  // ---- paint: boxes are drawn in top-k order, so for every pixel the LAST covering hit wins
+  // ---- paint: boxes are drawn in top-k order, so for every pixel the LAST covering hit wins.  This workgroup paints
+  //      pixels [p0, p_end): only the hits whose rectangle touches those rows are looked at, last painted first.
   float* hm = pc_hm + (size_t)b * 3 * HW;
   const int p_len = (HW + FR_SPLIT - 1) / FR_SPLIT;
-  const int p_end = min(HW, (part + 1) * p_len);
-  for (int p = part * p_len + tid; p < p_end; p += FR_THREADS) {
+  const int p0 = part * p_len, p_end = min(HW, (part + 1) * p_len);
+  if (wave == 0) {
+    const int y_lo = p0 / W, y_hi = p_end > p0 ? (p_end - 1) / W : y_lo;
+    int n_c = 0;
+    for (int base = 0; base < K; base += 64) {
+      const int i = K - 1 - (base + lane);
+      bool ok = false;
+      if (i >= 0) {
+        const FrBox& bx = box[i];
+        ok = bx.found && bx.p_y0 <= y_hi && bx.p_y1 > y_lo && bx.p_x1 > bx.p_x0 && bx.p_y1 > bx.p_y0;
+      }
+      const unsigned long long bal = __ballot(ok);
+      if (ok) cand[n_c + __popcll(bal & ((1ull << lane) - 1ull))] = (short)i;
+      n_c += (int)__popcll(bal);
+    }
+    if (lane == 0) s_ncand = n_c;
+  }
+  __syncthreads();
+  const int n_cand = s_ncand;
+  for (int p = p0 + tid; p < p_end; p += FR_THREADS) {
     const int y = p / W, x = p - y * W;
     float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
-    for (int i = K - 1; i >= 0; --i) {
-      const FrBox& bx = box[i];
-      if (bx.found && y >= bx.p_y0 && y < bx.p_y1 && x >= bx.p_x0 && x < bx.p_x1) {
+    for (int ci = 0; ci < n_cand; ++ci) {
+      const FrBox& bx = box[cand[ci]];
+      if (y >= bx.p_y0 && y < bx.p_y1 && x >= bx.p_x0 && x < bx.p_x1) {
         v0 = bx.val[0];
         v1 = bx.val[1];
         v2 = bx.val[2];
@@ -993,8 +1214,40 @@ extern "C" size_t cf_topk_workspace_bytes_nms(int B, int C, int H, int W, int K)
   return ((cf_topk_workspace_bytes(B, K) + 255) / 256) * 256 + map * sizeof(float);
 }
 
-extern "C" int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
-                             int32_t* inds, int32_t* classes, void* workspace, void* stream) {
+namespace {
+
+// position-weighted 64-bit checksum of a buffer of 32-bit words: sum of word[i] * (odd 32-bit weight of i) mod 2^64 - exact
+// integer arithmetic, independent of the order of summation, sensitive to WHERE a value sits (a plain sum is blind to swaps)
+__global__ __launch_bounds__(256) void checksum64_kernel(const uint32_t* __restrict__ x, long n, unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0ull;
+  const long step = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += step)
+    acc += (unsigned long long)x[i] * (unsigned long long)(((uint32_t)i * 2654435761u) | 1u);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += (unsigned long long)__shfl_xor((long long)acc, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+}  // namespace
+
+extern "C" int cf_checksum64(const void* x, long n_words, unsigned long long* out, void* stream) {
+  CF_REQUIRE(x && out && n_words >= 0, "cf_checksum64: null buffer or n_words=%ld", n_words);
+  hipStream_t st = (hipStream_t)stream;
+  if (const hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), st); e != hipSuccess) {
+    cf_set_error("cf_checksum64: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    return CF_ELAUNCH;
+  }
+  if (n_words == 0) return CF_OK;
+  const long blocks = (n_words + 1023) / 1024;
+  hipLaunchKernelGGL(checksum64_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st,
+                     static_cast<const uint32_t*>(x), n_words, out);
+  return cf_check_launch("cf_checksum64");
+}
+
+namespace {
+
+int topk_peaks_impl(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
+                    int32_t* inds, int32_t* classes, void* workspace, const unsigned long long* only_if, void* stream) {
   CF_REQUIRE(heat && scores && inds && classes && workspace, "cf_topk_peaks: null buffer");
   CF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cf_topk_peaks: bad geometry");
   CF_REQUIRE(K >= 1 && K <= TOPK_MAXK, "cf_topk_peaks: K=%d outside [1,%d]", K, TOPK_MAXK);
@@ -1007,19 +1260,37 @@ extern "C" int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int 
     float* sup = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + ((cf_topk_workspace_bytes(B, K) + 255) / 256) * 256);
     const long total = (long)B * C * H * W;
     const long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(nms_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, heat, sup, H, W, total);
+    hipLaunchKernelGGL(nms_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, heat, sup, H, W, total, only_if);
     heat = sup;
     nms = 0;
   }
+  static const int reg_off = [] { const char* e = getenv("CF_TOPK_REG"); return e ? atoi(e) == 0 : 0; }();   // (dev A/B: CF_TOPK_REG=0 = the 256-thread kernel)
+  const long slice_len = ((long)C * H * W + TOPK_SLICES - 1) / TOPK_SLICES;
   if (nms)
-    hipLaunchKernelGGL(topk_slice_kernel<true>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys);
+    hipLaunchKernelGGL(topk_slice_kernel<true>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys, only_if);
+  else if (slice_len <= (long)TOPK_RT * TOPK_RE && !reg_off)
+    hipLaunchKernelGGL(topk_slice_reg_kernel, dim3(B * TOPK_SLICES), dim3(TOPK_RT), 0, st, heat, C, H, W, K, keys, only_if);
   else
-    hipLaunchKernelGGL(topk_slice_kernel<false>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys);
+    hipLaunchKernelGGL(topk_slice_kernel<false>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys, only_if);
   const size_t merge_lds = (size_t)TOPK_SLICES * K * sizeof(uint64_t);
   static CfLdsLimit merge_limit;
   merge_limit.ensure(topk_merge_kernel, merge_lds, 65536);
-  hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(TOPK_MERGE_THREADS), merge_lds, st, keys, K, H * W, scores, inds, classes);
+  hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(TOPK_MERGE_THREADS), merge_lds, st, keys, K, H * W, scores, inds, classes, only_if);
   return cf_check_launch("cf_topk_peaks");
+}
+
+}  // namespace
+
+extern "C" int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
+                             int32_t* inds, int32_t* classes, void* workspace, void* stream) {
+  return topk_peaks_impl(heat, B, C, H, W, K, nms, scores, inds, classes, workspace, nullptr, stream);
+}
+
+extern "C" int cf_topk_peaks_if_changed(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
+                                        int32_t* inds, int32_t* classes, void* workspace,
+                                        const unsigned long long* sums, void* stream) {
+  CF_REQUIRE(sums != nullptr, "cf_topk_peaks_if_changed: null checksum pair");
+  return topk_peaks_impl(heat, B, C, H, W, K, nms, scores, inds, classes, workspace, sums, stream);
 }
 
 extern "C" int cf_frustum_assoc(const int32_t* inds, int K, const float* depth, const float* wh,
@@ -1030,9 +1301,37 @@ extern "C" int cf_frustum_assoc(const int32_t* inds, int K, const float* depth, 
   CF_REQUIRE(K >= 1 && K <= FR_MAXK, "cf_frustum_assoc: K=%d outside [1,%d]", K, FR_MAXK);
   CF_REQUIRE(B > 0 && H > 0 && W > 0, "cf_frustum_assoc: bad geometry");
   hipLaunchKernelGGL(frustum_kernel, dim3(B * FR_SPLIT), dim3(FR_THREADS), 0, (hipStream_t)stream, inds, K, depth, wh, dim,
-                     rot, calib, pc_dep, H, W, max_pc_dist, pc_hm, pc_hm_nhwc4,
-                     static_cast<unsigned*>(pc_hm_split8));
+                     rot, calib, pc_dep, H, W, max_pc_dist, pc_hm, pc_hm_nhwc4, static_cast<unsigned*>(pc_hm_split8),
+                     (const uint64_t*)nullptr, (float*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
   return cf_check_launch("cf_frustum_assoc");
+}
+
+// The chain between the two head launches in TWO launches instead of three: slice top-K of the raw heat map, then the
+// frustum kernel, which merges the slices' lists in its prologue (the merge launch and its 11 us are gone).
+extern "C" int cf_topk_frustum(const float* heat, int C, int K, const float* depth, const float* wh, const float* dim,
+                               const float* rot, const float* calib, const float* pc_dep, int B, int H, int W,
+                               float max_pc_dist, float* pc_hm, float* pc_hm_nhwc4, void* pc_hm_split8, float* scores,
+                               int32_t* inds, int32_t* classes, void* workspace, void* stream) {
+  CF_REQUIRE(heat && depth && wh && dim && rot && calib && pc_dep && pc_hm && workspace, "cf_topk_frustum: null buffer");
+  CF_REQUIRE((scores && inds && classes) || (!scores && !inds && !classes), "cf_topk_frustum: scores / inds / classes go together");
+  CF_REQUIRE(K >= 1 && K <= FR_MAXK && K <= TOPK_MAXK, "cf_topk_frustum: K=%d outside [1,%d]", K, FR_MAXK);
+  CF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cf_topk_frustum: bad geometry");
+  CF_REQUIRE((long)C * H * W >= K && (long)C * H * W < (1L << 31), "cf_topk_frustum: image of %ld elements", (long)C * H * W);
+  hipStream_t st = (hipStream_t)stream;
+  uint64_t* keys = static_cast<uint64_t*>(workspace);
+  static const int reg_off = [] { const char* e = getenv("CF_TOPK_REG"); return e ? atoi(e) == 0 : 0; }();
+  const long slice_len = ((long)C * H * W + TOPK_SLICES - 1) / TOPK_SLICES;
+  if (slice_len <= (long)TOPK_RT * TOPK_RE && !reg_off)
+    hipLaunchKernelGGL(topk_slice_reg_kernel, dim3(B * TOPK_SLICES), dim3(TOPK_RT), 0, st, heat, C, H, W, K, keys,
+                       (const unsigned long long*)nullptr);
+  else
+    hipLaunchKernelGGL(topk_slice_kernel<false>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys,
+                       (const unsigned long long*)nullptr);
+  const size_t lds = ((size_t)TOPK_SLICES * K + K) * sizeof(uint64_t);
+  hipLaunchKernelGGL(frustum_kernel, dim3(B * FR_SPLIT), dim3(FR_THREADS), lds, st, (const int32_t*)nullptr, K, depth, wh, dim,
+                     rot, calib, pc_dep, H, W, max_pc_dist, pc_hm, pc_hm_nhwc4, static_cast<unsigned*>(pc_hm_split8),
+                     (const uint64_t*)keys, scores, inds, classes);
+  return cf_check_launch("cf_topk_frustum");
 }
 
 extern "C" int cf_decode_gather(const cf_decode_args* a, void* stream) {

@@ -27,15 +27,18 @@ def _peaks_and_maps(outputs, K):
         raise NotImplementedError("uncertainty head (TRAIN.UNCERTAINTY_LOSS) is outside the hot path")
     heat = out["heatmap"]
     _, _, H, W = heat.shape
-    # the forward may have computed exactly these peaks already, beside its own launches (model._Plan.run: the heat map tensor
-    # carries them); they are used only for the very tensor they were computed from, unmodified since
+    # The forward may have computed exactly these peaks already, beside its own launches (model._Plan.run: the heat map tensor
+    # carries them with a checksum of the bits they were computed from).  They are used only for the very tensor object, and
+    # only while its contents still have that checksum: the map is summed again here and the top-k launches that follow
+    # compare the two sums ON THE DEVICE - equal: they return at once and the carried peaks stand; different (an in-place
+    # write, also one through `heat.data`, which bumps no version counter): they recompute into the same buffers.  The
+    # reference's fusionDecode always reads the map it is given (model/decode.py:38-57); so does this, at ~10 us instead of 75.
     cached = getattr(heat, "_cf_peaks", None)
-    try:
-        version = heat._version
-    except RuntimeError:                                       # (an inference-mode tensor: nothing is ever attached to one)
-        version = None
-    if cached is not None and cached[0] == K and cached[1] == version and cached[2] == heat.data_ptr():
-        scores, inds, classes = cached[3:]
+    if cached is not None and cached[0] == K and cached[1] == heat.data_ptr() and heat.is_contiguous() \
+            and not torch.cuda.is_current_stream_capturing():
+        pk_s, pk_i, pk_c, sums = cached[2:]
+        ops.checksum64(heat, out=sums[1:])
+        scores, inds, classes = ops.topk_peaks(heat, K, nms=True, out=(pk_s, pk_i, pk_c), only_if_changed=sums)
     else:
         scores, inds, classes = ops.topk_peaks(heat, K, nms=True)
     depth = out.get("depth2", out.get("depth"))

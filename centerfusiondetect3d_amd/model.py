@@ -401,6 +401,8 @@ class _Plan:
             a = ops.dcn_args(pd, x, om, 32, B, h, w, o, pd.n, ACT_RELU, precise=model.precise, workspace=ws,
                              in_scale=model._scale(p) if pd.out_scale > 0 else None)
             self.keep.append(a)
+            if out is not None:
+                self.feat_producer = a                       # the DCN that writes the feature map (ida(..., final_out=))
             self.inputs[p] = [x]
             self.step_index[p] = len(self.steps)
             self.step_flops[p] = 2.0 * B * h * w * pd.n * 9 * pd.c
@@ -442,6 +444,7 @@ class _Plan:
         self.h4, self.w4 = h4, w4
         self.in_step = None
         self.stem = None
+        self.feat_producer = None    # argument block of the DCN whose output is the feature map (set by dcn_node)
         self.debug = {}
         if part != "heads":
             # ---- backbone
@@ -489,12 +492,14 @@ class _Plan:
                     feat_in = buf(B, h4, w4, packing.MX_ROW, dtype=torch.uint8)
                 # ... written by the epilogue of the DCN that produces the map (f16x3 kernel, no K split at this size); a
                 # separate pass over the fp32 map only if that kernel is not in use
-                producer = [a for a in self.keep if isinstance(a, _lib.DcnArgs) and a.out == feat.data_ptr()
-                            and a.out_scale > 0 and a.N == 64 and a.N_pad == 64]
-                if producer and bool(model.pack_mx_fused):
-                    producer[-1].out_mx = feat_in.data_ptr()
-                    producer[-1].mx_scale = model._feat_scale
-                    producer[-1].workspace = None          # (the mx output and a K-split reduction exclude each other)
+                # (the feature map's DCN runs WITHOUT a K split whenever it also writes the heads' rows - the two exclude each
+                #  other - so on maps small enough for the split, <= 2048 pixels per image, the summation order of that one
+                #  layer depends on pack_mx_fused / heads_mx: same arithmetic, rounding differs)
+                pr = self.feat_producer
+                if pr is not None and pr.out_scale > 0 and pr.N == 64 and pr.N_pad == 64 and bool(model.pack_mx_fused):
+                    pr.out_mx = feat_in.data_ptr()
+                    pr.mx_scale = model._feat_scale
+                    pr.workspace = None
                 else:
                     self.step_index["feat.pack_mx"] = len(self.steps)
                     self.add_step((self.lib.cf_pack_feat_mx_scaled, feat.data_ptr(), 64, feat_in.data_ptr(), C.c_long(B * h4 * w4),
@@ -504,11 +509,10 @@ class _Plan:
                 # that produces it (f16x3 kernel); a separate split pass only if that kernel is not in use
                 if feat_in is None:
                     feat_in = buf(B, h4, w4, 2, 64, dtype=torch.bfloat16)
-                producer = [a for a in self.keep if isinstance(a, _lib.DcnArgs) and a.out == feat.data_ptr()
-                            and a.out_scale > 0 and a.N == 64]
-                if producer:
-                    producer[-1].out_split_bf16, producer[-1].split_stride = feat_in.data_ptr(), 64
-                    producer[-1].workspace = None          # (the split output and a K-split reduction exclude each other)
+                pr = self.feat_producer
+                if pr is not None and pr.out_scale > 0 and pr.N == 64:
+                    pr.out_split_bf16, pr.split_stride = feat_in.data_ptr(), 64
+                    pr.workspace = None                    # (the split output and a K-split reduction exclude each other)
                 else:
                     self.add_step((self.lib.cf_split_bf16, feat.data_ptr(), feat_in.data_ptr(), B * h4 * w4, 64, 64, 64))
             else:
@@ -623,7 +627,11 @@ class _Plan:
             self.tk_inds = buf(B, K, dtype=torch.int32)
             self.tk_cls = buf(B, K, dtype=torch.int32)
             self.tk_ws = buf(max(1, self.lib.cf_topk_workspace_bytes(B, K)), dtype=torch.uint8)
-            self.topk_step = len(self.steps); self.add_step(None)
+            # top-k of the raw heat map -> association (pointcloud.py:347-392): cf_topk_frustum (two launches: the merge of the slice
+            # lists runs in the association kernel's prologue) or, model.frustum_fused = False, cf_topk_peaks + cf_frustum_assoc (three)
+            self.topk_step = None
+            if not model.frustum_fused:
+                self.topk_step = len(self.steps); self.add_step(None)
             self.frustum_step = len(self.steps); self.add_step(None)
             ss = 256 * len(SECONDARY_HEADS)
             if fuse_all:
@@ -753,8 +761,11 @@ class _Plan:
                 pk_s = torch.empty((B, self.K), device=dev, dtype=torch.float32)
                 pk_i = torch.empty((B, self.K), device=dev, dtype=torch.int32)
                 pk_c = torch.empty((B, self.K), device=dev, dtype=torch.int32)
-                self.steps[self.peaks_step] = (lib.cf_topk_peaks, y["heatmap"].data_ptr(), B, heads["heatmap"], h4, w4, self.K, 2,
-                                               pk_s.data_ptr(), pk_i.data_ptr(), pk_c.data_ptr(), self.pk_ws.data_ptr())
+                pk_sum = torch.empty(2, device=dev, dtype=torch.int64)     # [checksum of the map the peaks belong to, decode's re-check]
+                n_words = B * heads["heatmap"] * h4 * w4
+                self.steps[self.peaks_step] = (_peaks_and_checksum, lib, (y["heatmap"].data_ptr(), B, heads["heatmap"], h4, w4, self.K, 2,
+                                               pk_s.data_ptr(), pk_i.data_ptr(), pk_c.data_ptr(), self.pk_ws.data_ptr()),
+                                               (y["heatmap"].data_ptr(), C.c_long(n_words), pk_sum.data_ptr()))
             else:
                 self.steps[self.peaks_step] = (_no_launch,)
         if self.in_step is not None:
@@ -765,16 +776,25 @@ class _Plan:
                 self.steps[self.in_step] = (lib.cf_nchw_to_nhwc4, x.data_ptr(), self.x4.data_ptr(), B, 3, H, W)
         if self.radar:
             pc_hm = new(3)
-            self.steps[self.topk_step] = (lib.cf_topk_peaks, y["heatmap"].data_ptr(), B, heads["heatmap"],
-                                          h4, w4, self.K, 0, self.tk_scores.data_ptr(),
-                                          self.tk_inds.data_ptr(), self.tk_cls.data_ptr(),
-                                          self.tk_ws.data_ptr())
-            self.steps[self.frustum_step] = (
-                lib.cf_frustum_assoc, self.tk_inds.data_ptr(), self.K, y["depth"].data_ptr(),
-                y["widthHeight"].data_ptr(), y["dimension"].data_ptr(), y["rotation"].data_ptr(),
-                calib.data_ptr(), pc_dep.data_ptr(), B, h4, w4,
-                C.c_float(float(model.config.DATASET.MAX_PC_DIST)), pc_hm.data_ptr(),
-                _lib.ptr(self.pc_hm4), _lib.ptr(self.pc_hm8))
+            if self.topk_step is None:
+                self.steps[self.frustum_step] = (
+                    lib.cf_topk_frustum, y["heatmap"].data_ptr(), heads["heatmap"], self.K, y["depth"].data_ptr(),
+                    y["widthHeight"].data_ptr(), y["dimension"].data_ptr(), y["rotation"].data_ptr(),
+                    calib.data_ptr(), pc_dep.data_ptr(), B, h4, w4,
+                    C.c_float(float(model.config.DATASET.MAX_PC_DIST)), pc_hm.data_ptr(),
+                    _lib.ptr(self.pc_hm4), _lib.ptr(self.pc_hm8), self.tk_scores.data_ptr(), self.tk_inds.data_ptr(),
+                    self.tk_cls.data_ptr(), self.tk_ws.data_ptr())
+            else:
+                self.steps[self.topk_step] = (lib.cf_topk_peaks, y["heatmap"].data_ptr(), B, heads["heatmap"],
+                                              h4, w4, self.K, 0, self.tk_scores.data_ptr(),
+                                              self.tk_inds.data_ptr(), self.tk_cls.data_ptr(),
+                                              self.tk_ws.data_ptr())
+                self.steps[self.frustum_step] = (
+                    lib.cf_frustum_assoc, self.tk_inds.data_ptr(), self.K, y["depth"].data_ptr(),
+                    y["widthHeight"].data_ptr(), y["dimension"].data_ptr(), y["rotation"].data_ptr(),
+                    calib.data_ptr(), pc_dep.data_ptr(), B, h4, w4,
+                    C.c_float(float(model.config.DATASET.MAX_PC_DIST)), pc_hm.data_ptr(),
+                    _lib.ptr(self.pc_hm4), _lib.ptr(self.pc_hm8))
             y["pc_hm_in"] = pc_dep[:, :1]
             y["pc_hm"] = pc_hm[:, 0, :, :].unsqueeze(1)
             for h in SECONDARY_HEADS:
@@ -788,13 +808,11 @@ class _Plan:
         self._launch(st)
         if self.peaks_step is not None and peaks_on:
             hm = y["heatmap"]
-            try:
-                hm._cf_peaks = (self.K, hm._version, hm.data_ptr(), pk_s, pk_i, pk_c)
-            except RuntimeError:                               # (torch.inference_mode(): no version counter to detect an in-place
-                pass                                           #  change of the heat map with - decode computes its own peaks)
+            # (decode.py re-checks the map's contents against pk_sum[0] on the device before it trusts the peaks)
+            hm._cf_peaks = (self.K, hm.data_ptr(), pk_s, pk_i, pk_c, pk_sum)
             side = getattr(self, "_side", None)
             if side is not None:                               # (allocator: these tensors were also used on the side stream)
-                for t in (hm, pk_s, pk_i, pk_c):
+                for t in (hm, pk_s, pk_i, pk_c, pk_sum):
                     t.record_stream(side)
         return [y]
 
@@ -803,6 +821,12 @@ class _Plan:
 def _no_launch(stream):
     """a plan step that issues nothing (status 0)"""
     return 0
+
+
+def _peaks_and_checksum(lib, topk_args, sum_args, stream):
+    """the decoder's NMS + top-k of the heat map and the checksum of the bits they were computed from (one plan step)"""
+    rc = lib.cf_topk_peaks(*topk_args, stream)
+    return rc if rc != 0 else lib.cf_checksum64(*sum_args, stream)
 
 
 # ----------------------------------------------------------------------------------- the module
@@ -859,6 +883,8 @@ class DLASeg(nn.Module):
                                           # in the two-stream step the two launches are 0.024 ms faster (round 5, 6 of 6 A/B pairs)
         self.heads_lanes = True  # fused heads: the decoder's NMS + top-k on a side stream beside the frustum path and the secondary
                                  # launch (_Plan heads section), handed to decode.py with the heat map
+        self.frustum_fused = True  # radar: top-k of the raw heat map + frustum association as cf_topk_frustum (2 launches, the merge in the
+                                   # association kernel's prologue) instead of cf_topk_peaks + cf_frustum_assoc (3); same bits
         self.proj_fuse = True    # the sub-tree that opens a level: `project` of the pooled input as k-steps of tree1.conv2
                                  # (cf_conv3x3_proj_f16x3) instead of a launch + a residual tensor; set before the first forward
         self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)

@@ -517,21 +517,44 @@ def nhwc_to_nchw(x, channels=None, out=None):
     return out
 
 
-def topk_peaks(heat, K=100, nms=False):
+def checksum64(t, out=None):
+    """Position-weighted 64-bit checksum of a contiguous device tensor's bits (cf_checksum64) -> 1-element int64 device tensor;
+    no host sync."""
+    _need_cuda(t)
+    nbytes = t.numel() * t.element_size()
+    if not t.is_contiguous() or nbytes % 4:
+        raise _lib.CfHipError("checksum64: contiguous tensor of a multiple of 4 bytes")
+    if out is None:
+        out = torch.empty(1, device=t.device, dtype=torch.int64)
+    _lib.check(_lib.load().cf_checksum64(t.data_ptr(), nbytes // 4, out.data_ptr(), _lib.stream_ptr()), "cf_checksum64")
+    return out
+
+
+def topk_peaks(heat, K=100, nms=False, out=None, only_if_changed=None):
     """(B,C,H,W) NCHW scores -> scores (B,K) f32, inds (B,K) i32, classes (B,K) i32.
-    nms: False / True (3x3 equality NMS first; True = the two-pass form, 1 = suppress on the fly)."""
+    nms: False / True (3x3 equality NMS first; True = the two-pass form, 1 = suppress on the fly).
+    out: (scores, inds, classes) to write into; only_if_changed: a 2-element int64 device tensor - the launches do nothing
+    when its two words are equal (cf_topk_peaks_if_changed: `out` then keeps what it held)."""
     _need_cuda(heat)
     if not heat.is_contiguous():
         heat = heat.contiguous()
     B, Cc, H, W = heat.shape
     dev = heat.device
-    scores = torch.empty((B, K), device=dev, dtype=torch.float32)
-    inds = torch.empty((B, K), device=dev, dtype=torch.int32)
-    classes = torch.empty((B, K), device=dev, dtype=torch.int32)
+    if out is not None:
+        scores, inds, classes = out
+    else:
+        scores = torch.empty((B, K), device=dev, dtype=torch.float32)
+        inds = torch.empty((B, K), device=dev, dtype=torch.int32)
+        classes = torch.empty((B, K), device=dev, dtype=torch.int32)
     lib = _lib.load()
     mode = int(nms) if nms in (0, 1, 2) and not isinstance(nms, bool) else (2 if nms else 0)
     size = lib.cf_topk_workspace_bytes_nms(B, Cc, H, W, K) if mode == 2 else lib.cf_topk_workspace_bytes(B, K)
     ws = torch.empty(max(1, size), device=dev, dtype=torch.uint8)
+    if only_if_changed is not None:
+        _lib.check(lib.cf_topk_peaks_if_changed(heat.data_ptr(), B, Cc, H, W, K, mode, scores.data_ptr(), inds.data_ptr(),
+                                                classes.data_ptr(), ws.data_ptr(), only_if_changed.data_ptr(),
+                                                _lib.stream_ptr()), "cf_topk_peaks_if_changed")
+        return scores, inds, classes
     _lib.check(lib.cf_topk_peaks(heat.data_ptr(), B, Cc, H, W, K, mode,
                                  scores.data_ptr(), inds.data_ptr(), classes.data_ptr(),
                                  ws.data_ptr(), _lib.stream_ptr()), "cf_topk_peaks")
@@ -555,6 +578,29 @@ def frustum_assoc(inds, depth, wh, dim, rot, calib, pc_dep, max_pc_dist=60.0, wa
                                             _lib.stream_ptr()),
                "cf_frustum_assoc")
     return (pc_hm, pc_hm_nhwc4) if want_nhwc4 else pc_hm
+
+
+def topk_frustum(heat, depth, wh, dim, rot, calib, pc_dep, K=100, max_pc_dist=60.0, want_nhwc4=False, want_split8=False,
+                 want_peaks=False):
+    """cf_topk_frustum: top-K of the raw heat map + frustum association in two launches (the slice lists are merged in the
+    association kernel's prologue) - the same pc_hm as topk_peaks(heat, K) followed by frustum_assoc, bit for bit.
+    -> pc_hm (B,3,H,W) [, nhwc4 (B,H,W,4)] [, split8 (B,H,W,2,8) bf16] [, (scores, inds, classes)]"""
+    _need_cuda(heat, depth, wh, dim, rot, calib, pc_dep)
+    B, Cc, H, W = heat.shape
+    dev = heat.device
+    ts = [t if t.is_contiguous() else t.contiguous() for t in (heat, depth, wh, dim, rot, calib, pc_dep)]
+    pc_hm = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
+    hm4 = torch.empty((B, H, W, 4), device=dev, dtype=torch.float32) if want_nhwc4 else None
+    hm8 = torch.empty((B, H, W, 2, 8), device=dev, dtype=torch.bfloat16) if want_split8 else None
+    peaks = (torch.empty((B, K), device=dev, dtype=torch.float32), torch.empty((B, K), device=dev, dtype=torch.int32),
+             torch.empty((B, K), device=dev, dtype=torch.int32)) if want_peaks else (None, None, None)
+    lib = _lib.load()
+    ws = torch.empty(max(1, lib.cf_topk_workspace_bytes(B, K)), device=dev, dtype=torch.uint8)
+    _lib.check(lib.cf_topk_frustum(ts[0].data_ptr(), Cc, K, *(t.data_ptr() for t in ts[1:]), B, H, W, float(max_pc_dist),
+                                   pc_hm.data_ptr(), _lib.ptr(hm4), _lib.ptr(hm8), *(_lib.ptr(t) for t in peaks),
+                                   ws.data_ptr(), _lib.stream_ptr()), "cf_topk_frustum")
+    out = [pc_hm] + ([hm4] if want_nhwc4 else []) + ([hm8] if want_split8 else []) + ([peaks] if want_peaks else [])
+    return out[0] if len(out) == 1 else tuple(out)
 
 
 def _decode_args(scores, inds, classes, maps: dict, H, W, out_hw, norm2d, det):

@@ -14,10 +14,9 @@ def getPcFrustumHeatmap(output, pc_dep, calib, config):
     """Same arguments / result as the reference: (B,3,H,W) map, zero where nothing was painted."""
     K = int(config.MODEL.K)
     B = pc_dep.shape[0]
-    _, inds, _ = ops.topk_peaks(output["heatmap"], K, nms=False)
-    return ops.frustum_assoc(inds, output["depth"], output["widthHeight"], output["dimension"],
-                             output["rotation"], calib.reshape(B, 3, 4).float(), pc_dep,
-                             float(config.DATASET.MAX_PC_DIST))
+    return ops.topk_frustum(output["heatmap"], output["depth"], output["widthHeight"], output["dimension"],
+                            output["rotation"], calib.reshape(B, 3, 4).float(), pc_dep, K,
+                            float(config.DATASET.MAX_PC_DIST))
 
 
 def getAffineTransform(center, scale, rotateFactor, outputSize):
@@ -56,7 +55,7 @@ def process_point_cloud_batch(pc_2d_list, pc_3d_list, calibs, trans_out, out_hw,
         p2[b, :, :n], p3[b, :c.shape[0], :n], cnt[b] = a[:3], c, n
     calibs = np.asarray(calibs, np.float64).reshape(B, 3, 4)
     trans = np.broadcast_to(np.asarray(trans_out, np.float64), (B, 2, 3)).copy()
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    t = lambda a: torch.from_numpy(np.array(a, copy=True, order="C")).to(device)        # (a private, writable copy: torch refuses read-only arrays with a warning)
     return ops.pillar_expand(t(p2), t(p3), t(cnt), t(calibs), t(trans), out_hw, pillar_dims)
 
 
@@ -77,7 +76,7 @@ def radar_to_pc_dep(radar_pcs, intrinsics, img_wh, calibs, trans_out, out_hw, ma
     for b, a in enumerate(arrs):
         pc[b, :a.shape[0], :a.shape[1]], cnt[b] = a, a.shape[1]
     K = np.ascontiguousarray(np.broadcast_to(np.asarray(intrinsics, np.float64).reshape(-1, 3, 3), (B, 3, 3)))
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    t = lambda a: torch.from_numpy(np.array(a, copy=True, order="C")).to(device)        # (a private, writable copy: torch refuses read-only arrays with a warning)
     pc_2d, pc_3d, counts = ops.radar_ingest(t(pc), t(cnt), t(K), img_wh, max_dist, z_offset, descending)
     calibs = np.asarray(calibs, np.float64).reshape(B, 3, 4)
     trans = np.broadcast_to(np.asarray(trans_out, np.float64), (B, 2, 3)).copy()

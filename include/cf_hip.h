@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CF_ABI_VERSION 6 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx, cf_dcn_args.out_mx; 5: cf_conv3x3_proj_f16x3, cf_stem_args.out_pool, cf_pack_conv_f16x3, cf_pack_dcn_f16; 6: in_scale (per-layer activation pre-scale of the f16x3 kernels) in cf_conv_args / cf_dcn_args / cf_stem_args, cf_dcn_args.mx_scale, cf_pack_feat_mx_scaled, cf_absmax_f32 */
+#define CF_ABI_VERSION 6 /* 2: cf_dcn_args.mask_activated, cf_nchw_to_nhwc, cf_spin_us; 3: cf_conv3x3_root_f16x3, stride 2 in cf_conv3x3_f16x3; 4: cf_head_fused_args.mx / first_scale, cf_pack_feat_mx, cf_dcn_args.out_mx; 5: cf_conv3x3_proj_f16x3, cf_stem_args.out_pool, cf_pack_conv_f16x3, cf_pack_dcn_f16; 6: in_scale (per-layer activation pre-scale of the f16x3 kernels) in cf_conv_args / cf_dcn_args / cf_stem_args, cf_dcn_args.mx_scale, cf_pack_feat_mx_scaled, cf_absmax_f32, cf_checksum64, cf_topk_peaks_if_changed, cf_topk_frustum */
 
 #define CF_OK 0
 #define CF_EINVAL (-22)
@@ -382,6 +382,16 @@ size_t cf_topk_workspace_bytes(int B, int K);
  * parallel pass into scratch memory behind the keys - workspace must then hold
  * cf_topk_workspace_bytes_nms(B, C, H, W, K) bytes.  (nms == 1 suppresses on the fly, no scratch.) */
 size_t cf_topk_workspace_bytes_nms(int B, int C, int H, int W, int K);
+/* (ABI 6) cf_checksum64: out[0] = sum over i < n_words of word[i] * w(i) mod 2^64, w(i) = ((uint32)i * 2654435761) | 1 - a
+ * position-weighted checksum of a device buffer read as 32-bit words (exact integer arithmetic; `out` is zeroed by the call).
+ * cf_topk_peaks_if_changed: cf_topk_peaks that does NOTHING when sums[0] == sums[1] (two checksums in device memory, tested
+ * on the device: no host sync) and recomputes scores / inds / classes otherwise.  Together they let the host keep the peaks
+ * the forward computed beside its own launches (model.py: heads_lanes) and still honour ANY later change of the heat map -
+ * also one made through `tensor.data`, which no version counter sees - as the reference's fusionDecode would
+ * (model/decode.py:38-57: it always reads the map it is given).  No reference counterpart. */
+int cf_checksum64(const void* x, long n_words, unsigned long long* out, void* stream);
+int cf_topk_peaks_if_changed(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores, int32_t* inds,
+                             int32_t* classes, void* workspace, const unsigned long long* sums, void* stream);
 int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
                   int32_t* inds, int32_t* classes, void* workspace, void* stream);
 
@@ -395,6 +405,16 @@ int cf_frustum_assoc(const int32_t* inds, int K, const float* depth, const float
                      const float* dim, const float* rot, const float* calib, const float* pc_dep,
                      int B, int H, int W, float max_pc_dist, float* pc_hm, float* pc_hm_nhwc4,
                      void* pc_hm_split8, void* stream);
+
+/* (ABI 6) cf_topk_frustum: cf_topk_peaks(heat, nms = 0) followed by cf_frustum_assoc on its peaks - the chain between the
+ * primary and the secondary head launches (utils/pointcloud.py:347-392: topk of the un-NMS'd heat map, then the association
+ * loop) - as TWO launches instead of three: the slice top-K, then the association kernel, which merges the slices' sorted
+ * lists in its prologue.  heat (B,C,H,W); workspace: cf_topk_workspace_bytes(B, K) bytes; scores / inds / classes (B,K):
+ * optional (all three or none) - the peaks as cf_topk_peaks would return them.  Same results as the two calls, bit for bit. */
+int cf_topk_frustum(const float* heat, int C, int K, const float* depth, const float* wh, const float* dim,
+                    const float* rot, const float* calib, const float* pc_dep, int B, int H, int W, float max_pc_dist,
+                    float* pc_hm, float* pc_hm_nhwc4, void* pc_hm_split8, float* scores, int32_t* inds, int32_t* classes,
+                    void* workspace, void* stream);
 
 /* cf_pillar_expand: radar points -> pc_dep (B,3,H,W) by pillar expansion (fp64 geometry).
  * replaces dataset/generic_dataset.py:738-942 (processPointCloud / transformPointCloud /

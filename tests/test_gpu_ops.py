@@ -217,17 +217,20 @@ def test_topk_overflow_path_and_odd_shapes(dev):
     _check_topk(dev, neg, 50, False)
 
 
+@pytest.mark.parametrize("stride,n_lanes", [(256, 90), (1024, 360)], ids=["kernel_256_threads", "register_kernel_1024_threads"])
 @pytest.mark.parametrize("n_big", [300, 3000, 6000])
-def test_topk_candidate_counts_across_the_three_ordering_paths(dev, n_big):
-    """A slice (14,000 elements at 10 x 112 x 200, scanned by 256 threads with stride 256) whose large values all sit
-    in 90 of the 256 lanes: the K-th largest LOCAL maximum is then small and every large value is a candidate -
-    300 of them are ordered by rank counting, 3,000 by the bitonic sort (> 1,024), 6,000 (> 4,096, the LDS capacity)
-    go through the radix select first.  All three must give the oracle's top-K, also behind the NMS."""
+def test_topk_candidate_counts_across_the_three_ordering_paths(dev, n_big, stride, n_lanes):
+    """A slice (14,000 elements at 10 x 112 x 200, scanned by 256 threads with stride 256 - behind the NMS - or by 1,024
+    threads with stride 1,024 and group maxima over 4 neighbouring threads - the register-cached kernel of the plain top-K)
+    whose large values all sit in fewer than K of the lanes / groups: the K-th largest LOCAL maximum is then small and every
+    large value is a candidate - 300 of them are ordered by rank counting, 3,000 by the bitonic sort (256-thread kernel:
+    > 1,024) or still by rank counting, 6,000 (> 4,096, the LDS capacity; 4,900 with stride 1,024) go through the radix
+    select first.  All must give the oracle's top-K, also behind the NMS."""
     g = torch.Generator().manual_seed(n_big)
     heat = torch.rand(2, 10, 112, 200, generator=g) * 0.1
     flat = heat[1].view(-1)                                       # image 1, slice 0 = its first 14,000 elements
     lanes = torch.arange(14000)
-    pool = lanes[lanes % 256 < 90]
+    pool = lanes[lanes % stride < n_lanes]
     pick = pool[torch.randperm(pool.numel(), generator=g)[:n_big]] if n_big <= pool.numel() else pool
     flat[pick] = torch.rand(pick.numel(), generator=g) * 0.4 + 0.5
     _check_topk(dev, heat, 100, False)
@@ -253,6 +256,40 @@ def test_frustum_bit_exact_vs_reference_golden(dev, golden_dir, seed):
     assert np.array_equal(flat[nz], g["nz_val"])
     assert np.array_equal(hm4[..., :3].cpu().numpy(), pc_hm.permute(0, 2, 3, 1).cpu().numpy())
     assert float(hm4[..., 3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("seed,B,H,W", [(0, 2, 112, 200), (1, 2, 112, 200), (2, 2, 112, 200), (7, 3, 28, 50), (8, 1, 224, 400)])
+def test_topk_frustum_two_launches_equal_the_three(dev, seed, B, H, W):
+    """cf_topk_frustum (slice top-K + association with the merge in its prologue; model.frustum_fused) against
+    cf_topk_peaks + cf_frustum_assoc: peaks, painted map, its NHWC copy and its split-bf16 rows, bit for bit - on the
+    reference-golden cases (borders, overlaps, gate misses), a small map and a 224 x 400 one (the 256-thread slice kernel)."""
+    from centerfusiondetect3d_amd import ops
+    y, pc_dep, calib = cases.frustum_case(seed, B=B, H=H, W=W)
+    d = {k: v.to(dev) for k, v in y.items()}
+    s, inds, cls = ops.topk_peaks(d["heatmap"], 100, nms=False)
+    hm8_ref = torch.zeros((B, H, W, 2, 8), device=dev, dtype=torch.bfloat16)
+    pc_ref, hm4_ref = ops.frustum_assoc(inds, d["depth"], d["widthHeight"], d["dimension"], d["rotation"], calib.to(dev),
+                                        pc_dep.to(dev), 60.0, want_nhwc4=True, pc_hm_split8=hm8_ref)
+    pc_hm, hm4, hm8, (s2, i2, c2) = ops.topk_frustum(d["heatmap"], d["depth"], d["widthHeight"], d["dimension"], d["rotation"],
+                                                     calib.to(dev), pc_dep.to(dev), 100, 60.0, want_nhwc4=True,
+                                                     want_split8=True, want_peaks=True)
+    assert torch.equal(s2, s) and torch.equal(i2, inds) and torch.equal(c2, cls)
+    assert torch.equal(pc_hm, pc_ref) and int((pc_ref != 0).sum()) > 0
+    assert torch.equal(hm4, hm4_ref)
+    assert torch.equal(hm8.view(torch.int16), hm8_ref.view(torch.int16))
+    # a large ROI (a box covering most of the map: several rounds of the four-loads-per-lane search) with ties in depth
+    big = {k: v.clone() for k, v in d.items()}
+    big["widthHeight"][:] = max(H, W) * 0.8
+    pcd = pc_dep.clone()
+    pcd[:, 0][pcd[:, 0] != 0] = 20.0                                # every radar return at the same depth: the FIRST one in row-major order wins
+    big["depth"][:] = 20.0
+    _, inds_b, _ = ops.topk_peaks(big["heatmap"], 100, nms=False)
+    ref_b = frustum_ref.pc_frustum_heatmap({k: v.cpu() for k, v in big.items()}, pcd, calib, 100, 60.0)
+    got_b = ops.topk_frustum(big["heatmap"], big["depth"], big["widthHeight"], big["dimension"], big["rotation"],
+                             calib.to(dev), pcd.to(dev), 100, 60.0)
+    assert np.array_equal(got_b.cpu().numpy(), ref_b.numpy())
+    assert torch.equal(got_b, ops.frustum_assoc(inds_b, big["depth"], big["widthHeight"], big["dimension"], big["rotation"],
+                                                calib.to(dev), pcd.to(dev), 60.0))
 
 
 def test_frustum_no_radar_and_single_box(dev):

@@ -262,7 +262,7 @@ def test_detector_first_batch_goes_through_the_guard(dev):
     from tests.golden import cases_dataset as cd
     H, W, B = 128, 160, 2
     cfg = centerfusion_middle_config((H, W))
-    sd = _boost(cases.tuned_state_dict(radar=True, seed=0), "level5", 65536.0)   # (uint8-noise frames excite level 5 less than randn images)
+    sd = _boost(cases.tuned_state_dict(radar=True, seed=0), "feat", 4096.0)      # (the feature map: every head reads it)
     rs = np.random.RandomState(3)
     frames = [rs.randint(0, 256, (450, 800, 3)).astype(np.uint8) for _ in range(B)]
     K3 = cd.NUSC_K * 0.5
@@ -276,11 +276,11 @@ def test_detector_first_batch_goes_through_the_guard(dev):
         model.load_state_dict(sd)
         return Detector(cfg, model=model, device=dev, range_policy=policy)
 
-    with pytest.raises(_lib.CfHipError, match=r"base\.level5\.tree1\.conv2"):
+    with pytest.raises(_lib.CfHipError, match=r"heads\.primary\.0"):
         detector("raise").run(frames, infos, sweeps)
     det = detector("calibrate")
     ret = det.run(frames, infos, sweeps)
-    assert det.model._range_checked and det.model.activation_scales()["base.level5.tree1.conv2"] < 16.0
+    assert det.model._range_checked and det.model.activation_scales()["heads.primary.0"] < 16.0
     plans = dict(det.model._plans)
     ret2 = det.run(frames, infos, sweeps)                              # second batch: no second calibration (plans survive)
     assert all(det.model._plans.get(k) is v for k, v in plans.items())

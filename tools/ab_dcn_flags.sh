@@ -7,9 +7,11 @@ OUT=gpurun_out/dcn_flags.txt
 PKG=centerfusiondetect3d_amd
 SHAPES=${SHAPES:-"16,64,64,112,200 8,64,64,112,200 16,128,64,56,100 8,128,64,56,100 8,256,64,28,50"}
 relink() {
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$PKG/csrc $1 -c $PKG/csrc/cf_gemm_f16.hip -o $PKG/_build/cf_gemm_f16.o 2>/dev/null
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$PKG/csrc ${1:+-DCF_DEV_ARMS} $1 -c $PKG/csrc/cf_gemm_f16.hip -o $PKG/_build/cf_gemm_f16.o
   hipcc --offload-arch=gfx950 -shared -fPIC $PKG/_build/*.o -o $PKG/libcfhip.so
 }
+# whatever happens (a failed arm build, a failed bench run under set -e): the in-tree library is the DEFAULT build again on exit
+trap 'relink ""' EXIT
 for arm in "$@" ; do
   echo "== flags: [$arm]" >> $OUT
   relink "$arm"

@@ -6,9 +6,11 @@ OUT=gpurun_out/heads_arms.txt
 : > $OUT
 PKG=centerfusiondetect3d_amd
 relink() {
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$PKG/csrc $1 -c $PKG/csrc/cf_heads.hip -o $PKG/_build/cf_heads.o 2>/dev/null
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$PKG/csrc ${1:+-DCF_DEV_ARMS} $1 -c $PKG/csrc/cf_heads.hip -o $PKG/_build/cf_heads.o
   hipcc --offload-arch=gfx950 -shared -fPIC $PKG/_build/*.o -o $PKG/libcfhip.so
 }
+# whatever happens (a failed arm build, a failed bench run under set -e): the in-tree library is the DEFAULT build again on exit
+trap 'relink ""' EXIT
 for arm in "$@" ; do
   echo "== arm: [$arm]" >> $OUT
   relink "$arm"

@@ -4,6 +4,8 @@
 set -e
 P=centerfusiondetect3d_amd
 cp $P/libcfhip.so /tmp/new.so
+# whatever happens: the in-tree library is the new build again on exit
+trap 'cp /tmp/new.so $P/libcfhip.so' EXIT
 for i in 1 2 3; do
   cp /tmp/new.so $P/libcfhip.so; python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/ab_lib_new.txt
   cp $P/_ab/libcfhip_prev.so $P/libcfhip.so; python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 >> gpurun_out/ab_lib_prev.txt

@@ -1,4 +1,4 @@
-"""Dev tool (GPU box): phase cycle counts of conv3x3_f16x3_kernel (build with CF_EXTRA_FLAGS=-DCF_CONV3_PROF first;
+"""Dev tool (GPU box): phase cycle counts of conv3x3_f16x3_kernel (build with CF_EXTRA_FLAGS='-DCF_DEV_ARMS -DCF_CONV3_PROF' first;
 outputs are then overwritten by the counters).  Phases of thread 0 per workgroup: 0 = prologue (first patch),
 1 = tap loops, 2 = end of round (second half of the next patch + barrier), 3 = epilogue.
    python tools/prof_conv3.py B,C,N,H,W [...]"""

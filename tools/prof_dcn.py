@@ -1,4 +1,4 @@
-"""Dev tool (GPU box): phase cycle counts of dcn_f16x3_kernel (build with CF_EXTRA_FLAGS=-DCF_DCN_PROF first; the first
+"""Dev tool (GPU box): phase cycle counts of dcn_f16x3_kernel (build with CF_EXTRA_FLAGS='-DCF_DEV_ARMS -DCF_DCN_PROF' first; the first
 output values of every tile are then overwritten by the counters).  Phases of thread 0 per workgroup: 0 = sampling
 descriptors, 1 = K loop, 2 = epilogue.     python tools/prof_dcn.py [B,C,N,H,W ...]"""
 import os, sys
