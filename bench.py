@@ -576,6 +576,10 @@ def main():
                     help="A/B: the level-2 Tree's max-pool as its own launch instead of a second output of the stem (model.stem_pool)")
     ap.add_argument("--no-heads-lanes", action="store_true",
                     help="A/B: the decoder's NMS + top-k behind the forward on the caller's stream instead of beside the secondary heads (model.heads_lanes = False)")
+    ap.add_argument("--peaks-behind-primary", action="store_true",
+                    help="A/B: the decoder's top-k lane starts behind the primary head launch (round 5) instead of behind the frustum chain")
+    ap.add_argument("--no-frustum-fused", action="store_true",
+                    help="A/B: cf_topk_peaks + cf_frustum_assoc (three launches) between the head launches instead of cf_topk_frustum (model.frustum_fused = False)")
     ap.add_argument("--root-fuse-children", action="store_true",
                     help="A/B: conv2 + Root in one launch also for the Roots that read the Tree's children (model.root_fuse_children)")
     ap.add_argument("--lanes-max-frames", type=int, default=None,
@@ -653,6 +657,10 @@ def main():
         model.stem_pool = False
     if args.root_fuse_children:
         model.root_fuse_children = True
+    if args.no_frustum_fused:
+        model.frustum_fused = False
+    if args.peaks_behind_primary:
+        model.peaks_behind_frustum = False
     if args.lanes_max_frames is not None:
         model.lanes_max_frames = args.lanes_max_frames
     if args.no_heads_lanes:

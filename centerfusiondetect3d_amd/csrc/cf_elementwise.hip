@@ -210,7 +210,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) best = max(best, (unsigned)__shfl_xor((int)best, o, 64));
-  if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
+  __shared__ unsigned part[4];                   // one atomic per block (same-address atomics are served one by one)
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    best = max(max(part[0], part[1]), max(part[2], part[3]));
+    if (best) atomicMax(out, best);
+  }
 }
 
 __global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks) {
@@ -304,7 +310,7 @@ extern "C" int cf_absmax_f32(const float* x, long M, int C, int stride, float* o
   if (M == 0) return CF_OK;
   const long n = M * C;
   const long blocks = (n / 4 + 255) / 256;
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, x, M, C, stride,
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 512 ? 512 : blocks)), dim3(256), 0, st, x, M, C, stride,
                      reinterpret_cast<unsigned*>(out));
   return cf_check_launch("cf_absmax_f32");
 }

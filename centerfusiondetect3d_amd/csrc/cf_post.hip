@@ -13,6 +13,8 @@
 
 namespace {
 
+typedef uint32_t u32x4p __attribute__((ext_vector_type(4)));
+
 constexpr int TOPK_THREADS = 256;   // slice kernel
 constexpr int TOPK_MERGE_THREADS = 1024;
 constexpr int TOPK_CAP = 4096;      // candidate keys kept in LDS (32 KiB)
@@ -68,13 +70,9 @@ __device__ void bitonic_sort_desc(uint64_t* keys, int P) {
 
 // heat * (maxpool3x3(heat) == heat) as its own fully parallel pass (cf_topk_peaks, nms == 2): one
 // thread per element, rows of the 3x3 window served by L1/L2.
-// `only_if` (all three top-k kernels; cf_topk_peaks_if_changed): two 64-bit words in device memory - when they are EQUAL the
-// launch does nothing (the caller's cached result still belongs to the map); nullptr = unconditional.  A uniform scalar test.
-#define CF_SKIP_IF_UNCHANGED(p) if ((p) != nullptr && (p)[0] == (p)[1]) return
 
 __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ heat, float* __restrict__ out, int H,
-                                                  int W, long total, const unsigned long long* __restrict__ only_if) {
-  CF_SKIP_IF_UNCHANGED(only_if);
+                                                  int W, long total) {
   const long N = (long)H * W;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long plane = i / N;
@@ -87,7 +85,15 @@ __device__ __forceinline__ void rank_select_desc(const uint64_t* keys, int n, in
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const uint64_t mine = keys[i];
     int rank = 0;
-    for (int j = 0; j < n; ++j) rank += keys[j] > mine ? 1 : 0;     // (same address across the wave: LDS broadcast)
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {                                    // eight reads in flight (same address across the wave: LDS broadcast)
+      uint64_t o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = keys[j + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rank += o[e] > mine ? 1 : 0;
+    }
+    for (; j < n; ++j) rank += keys[j] > mine ? 1 : 0;
     if (rank < K) out[rank] = mine;
   }
 }
@@ -106,22 +112,21 @@ __device__ __forceinline__ void rank_select_desc(const uint64_t* keys, int n, in
 //     against the ~45 barrier-separated passes of a bitonic sort), more than that (adversarial inputs) by the sort.
 // If more than 4096 elements exceed L (adversarial input), the exact K-th value is found by a
 // 4 x 8-bit radix select and step B is repeated with it.
+// (a device function of a TOPK_THREADS workgroup: slice `slice` of image `img_i` -> out_keys + (img_i * TOPK_SLICES + slice) * K;
+//  the kernel below runs one slice per workgroup, topk_fallback_kernel all slices of an image one after the other)
 template <bool NMS>
-__global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* __restrict__ heat, int C, int H,
-                                                                  int W, int K, uint64_t* __restrict__ out_keys,
-                                                                  const unsigned long long* __restrict__ only_if) {
-  CF_SKIP_IF_UNCHANGED(only_if);
-  __shared__ uint64_t keys[TOPK_CAP];
+__device__ __forceinline__ void topk_slice_body(const float* __restrict__ heat, int C, int H, int W, int K,
+                                                uint64_t* __restrict__ out_keys, int img_i, int slice) {
+  __shared__ __attribute__((aligned(16))) uint64_t keys[TOPK_CAP];
   __shared__ uint32_t hist[256];
   __shared__ uint32_t wave_cnt[TOPK_THREADS / 64];
   __shared__ uint32_t s_gt, s_sel[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HW = H * W, N = C * HW;
-  const int img_i = blockIdx.x / TOPK_SLICES, slice = blockIdx.x % TOPK_SLICES;
   const float* img = heat + (size_t)img_i * N;
   const int len = (N + TOPK_SLICES - 1) / TOPK_SLICES;
   const int lo = min(slice * len, N), hi = min(lo + len, N);
-  uint64_t* out = out_keys + (size_t)blockIdx.x * K;
+  uint64_t* out = out_keys + ((size_t)img_i * TOPK_SLICES + slice) * K;
   const int n = hi - lo;
   if (n <= K) {  // tiny slice: everything is a candidate
     for (int i = tid; i < TOPK_MAXK; i += TOPK_THREADS)
@@ -158,10 +163,13 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* _
   lm[tid] = lmax;
   __syncthreads();
   {
+    const u32x4p* l4 = reinterpret_cast<const u32x4p*>(lm);       // (keys[] is 16-byte aligned; eight 16-byte reads in flight)
     int rank = 0;
-    for (int j = 0; j < TOPK_THREADS; ++j) {
-      const uint32_t o = lm[j];
-      rank += (o > lmax || (o == lmax && j < tid)) ? 1 : 0;
+#pragma unroll 8
+    for (int j4 = 0; j4 < TOPK_THREADS / 4; ++j4) {
+      const u32x4p o = l4[j4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rank += (o[e] > lmax || (o[e] == lmax && 4 * j4 + e < tid)) ? 1 : 0;
     }
     if (rank == K - 1) s_sel[0] = lmax;
   }
@@ -263,22 +271,26 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* _
   for (int j = tid; j < K; j += TOPK_THREADS) out[j] = keys[j];
 }
 
+template <bool NMS>
+__global__ __launch_bounds__(TOPK_THREADS) void topk_slice_kernel(const float* __restrict__ heat, int C, int H,
+                                                                  int W, int K, uint64_t* __restrict__ out_keys) {
+  topk_slice_body<NMS>(heat, C, H, W, K, out_keys, blockIdx.x / TOPK_SLICES, blockIdx.x % TOPK_SLICES);
+}
+
 // Pass 1, register-cached form (maps of up to TOPK_RT * TOPK_RE elements per slice - every map of the 448 x 800 configurations):
 // 1024 threads per slice, each holds its <= 16 elements in registers, so the map is read ONCE with every load of the slice
 // in flight at the same time (the 256-thread kernel above walks the slice twice, four loads per thread at a time: 14 + 14
 // dependent rounds of memory latency per launch - 35 us of the chain between the two head launches).  Same algorithm,
-// same keys: A. lower bound L = the K-th largest of 256 GROUP maxima (a group = 4 neighbouring threads: 256 distinct
+// same keys: A. lower bound L = the K-th largest of G GROUP maxima (a group = 1024 / G neighbouring threads: G >= K distinct
 // elements, so at least K elements are >= L); B. everything above L into LDS - from the registers; ties / plateaus and the
 // adversarial case exactly as above, on the registers; C. rank counting.
 constexpr int TOPK_RT = 1024;
 constexpr int TOPK_RE = 16;
 
 __global__ __launch_bounds__(TOPK_RT) void topk_slice_reg_kernel(const float* __restrict__ heat, int C, int H, int W, int K,
-                                                                 uint64_t* __restrict__ out_keys,
-                                                                 const unsigned long long* __restrict__ only_if) {
-  CF_SKIP_IF_UNCHANGED(only_if);
+                                                                 uint64_t* __restrict__ out_keys) {
   __shared__ uint64_t keys[TOPK_CAP];
-  __shared__ uint32_t gmax[256];
+  __shared__ __attribute__((aligned(16))) uint32_t gmax[256];
   __shared__ uint32_t hist[256];
   __shared__ uint32_t wave_cnt[TOPK_RT / 64];
   __shared__ uint32_t s_gt, s_sel[2];
@@ -308,26 +320,57 @@ __global__ __launch_bounds__(TOPK_RT) void topk_slice_reg_kernel(const float* __
   }
 #pragma unroll
   for (int e = 0; e < TOPK_RE; ++e) lmax = max(lmax, u[e]);
-  // ---- A: the K-th largest of the 256 group maxima (ties ranked by group id)
+  // ---- A: the K-th largest of the G group maxima (ties ranked by group id).  G = 128 groups of 8 neighbouring threads for
+  //      K <= 128, else 256 groups of 4: the rank counting is G^2 compares of VALU work per workgroup - 65,536 of them at
+  //      G = 256 were 7 of this kernel's 18 us - and every candidate's count is split over the 1024 / G threads of its group.
+  const int P = K <= 128 ? 8 : 4, G = TOPK_RT / P;
   {
     uint32_t m = lmax;
     m = max(m, (uint32_t)__shfl_xor((int)m, 1));
     m = max(m, (uint32_t)__shfl_xor((int)m, 2));
-    if ((tid & 3) == 0) gmax[tid >> 2] = m;
+    if (P == 8) m = max(m, (uint32_t)__shfl_xor((int)m, 4));
+    if ((tid & (P - 1)) == 0) gmax[tid / P] = m;
   }
-  if (tid == 0) s_sel[0] = 0u;                   // (fewer than K non-empty groups - a slice of < 4 K elements: everything is taken)
+  if (tid == 0) s_sel[0] = 0u;                   // (fewer than K non-empty groups - a slice of < P K elements: everything is taken)
   __syncthreads();
-  if (tid < 256) {
-    const uint32_t mine = gmax[tid];
+  {
+    const int c = tid / P, part = tid & (P - 1), per = G / P;      // candidate c against entries [part * per, (part + 1) * per)
+    const uint32_t mine = gmax[c];
+    const u32x4p* g4 = reinterpret_cast<const u32x4p*>(gmax + part * per);
     int rank = 0;
-    for (int j = 0; j < 256; ++j) {
-      const uint32_t o = gmax[j];
-      rank += (o > mine || (o == mine && j < tid)) ? 1 : 0;
+#pragma unroll 4
+    for (int j4 = 0; j4 < per / 4; ++j4) {
+      const u32x4p o = g4[j4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rank += (o[e] > mine || (o[e] == mine && part * per + 4 * j4 + e < c)) ? 1 : 0;
     }
-    if (rank == K - 1) s_sel[0] = mine;
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    if (P == 8) rank += __shfl_xor(rank, 4);
+    if (part == 0 && rank == K - 1) s_sel[0] = mine;
   }
   __syncthreads();
   uint32_t L = s_sel[0];
+  __syncthreads();
+
+  // ---- B0 (the common case): everything >= the bound - at least K elements - fits the candidate buffer: rank counting over
+  //      them orders ties at L by index as well (the key's low word), so no tie pass is needed (it cost 8 barrier-separated
+  //      rounds on average: 8 of this kernel's 18 us).  A plateau at L (a clamped map) overflows the buffer and takes B below.
+  if (tid == 0) s_gt = 0;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < TOPK_RE; ++e) {
+    const int i = lo + tid + e * TOPK_RT;
+    if (i < hi && u[e] >= L) {
+      const uint32_t pos = atomicAdd(&s_gt, 1u);
+      if (pos < TOPK_CAP) keys[pos] = ((uint64_t)u[e] << 32) | (uint32_t)(~(uint32_t)i);
+    }
+  }
+  __syncthreads();
+  if (s_gt <= TOPK_CAP) {
+    rank_select_desc(keys, (int)s_gt, K, out);
+    return;
+  }
   __syncthreads();
 
   // ---- B: collect everything strictly above the bound
@@ -408,49 +451,48 @@ __global__ __launch_bounds__(TOPK_RT) void topk_slice_reg_kernel(const float* __
 }
 
 // Merge of the TOPK_SLICES sorted key lists of one image (keys[] in LDS, list o at keys + o * K; descending, keys unique
-// over the image): best[r] = the key of global rank r < K.  The rank of an element is its position in its own list plus, for
-// every other list, the number of keys above it; that count is found in TWO dependent steps - the list's pivots (every R-th
-// key, R ~ sqrt(K)) and the R keys of the block the pivots point at - with all reads of a step independent of each other
-// (a binary search is 7 dependent LDS round trips per list: the merge took 11.5 us that way).  Whole workgroup; syncs.
-__device__ __forceinline__ void merge_sorted_lists(const uint64_t* keys, int K, uint64_t* __restrict__ best) {
-  const int total = TOPK_SLICES * K;
-  int R = 1;
-  while (R * R < K) ++R;
-  const int n_piv = (K + R - 1) / R;
-  for (int i = threadIdx.x; i < total; i += blockDim.x) {
-    const int sl = i / K, pos = i - sl * K;
-    const uint64_t mine = keys[i];
-    int rank = pos;
-    for (int o = 0; o < TOPK_SLICES; ++o) {
-      if (o == sl) continue;
-      const uint64_t* lst = keys + o * K;
-      int c1 = 0;                                  // pivots above mine (monotone: the first c1 of them)
-      for (int j = 0; j < n_piv; ++j) c1 += lst[min((j + 1) * R, K) - 1] > mine ? 1 : 0;
-      const int start = c1 * R;                    // every key before `start` is above mine, the block's pivot (if any) is not
-      int c2 = 0;
-      for (int q = 0; q < R; ++q) c2 += (start + q < K && lst[min(start + q, K - 1)] > mine) ? 1 : 0;
-      rank += start < K ? start + c2 : K;
-      if (rank >= K) break;
+// over the image - zero padding of tiny slices excepted, which ties only with itself) as a TREE of pairwise merges that each
+// keep the top K: 16 -> 8 -> 4 -> 2 -> 1 lists, ping-pong between keys[0 .. 16 K) and tmp[0 .. 8 K).  An element's rank in
+// the merge of its pair = its position + the number of the partner's keys above it (one 7-step binary search): 3,000
+// searches over the four levels instead of the 24,000 of ranking every key against all 15 other lists at once (11.5 us as
+// its own launch).  -> pointer to the K merged keys (in keys[] or tmp[]).  Whole workgroup; ends with a barrier.
+__device__ __forceinline__ const uint64_t* merge_sorted_lists(uint64_t* keys, uint64_t* tmp, int K) {
+  uint64_t* src = keys;
+  uint64_t* dst = tmp;
+  for (int lists = TOPK_SLICES; lists > 1; lists >>= 1) {
+    const int total = lists * K;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int sl = i / K, pos = i - sl * K;
+      const uint64_t mine = src[i];
+      const uint64_t* lst = src + (sl ^ 1) * K;          // the partner list
+      int lo = 0, hi = K;                                // first position whose key is NOT above mine
+      // (equal keys exist only as zero padding; the odd list of a pair counts them as above, so a tie takes two ranks)
+      const bool ge = (sl & 1) != 0;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint64_t o = lst[mid];
+        if (o > mine || (ge && o == mine)) lo = mid + 1; else hi = mid;
+      }
+      const int rank = pos + lo;
+      if (rank < K) dst[(sl >> 1) * K + rank] = mine;
     }
-    if (rank < K) best[rank] = mine;
+    __syncthreads();
+    uint64_t* t = src; src = dst; dst = t;
   }
-  __syncthreads();
+  return src;
 }
 
 // Pass 2: merge the TOPK_SLICES sorted key lists of one image and emit scores / pixel / class.
 __global__ __launch_bounds__(TOPK_MERGE_THREADS) void topk_merge_kernel(const uint64_t* __restrict__ in_keys,
                                                                         int K, int HW, float* __restrict__ scores,
                                                                         int32_t* __restrict__ inds,
-                                                                        int32_t* __restrict__ classes,
-                                                                        const unsigned long long* __restrict__ only_if) {
-  CF_SKIP_IF_UNCHANGED(only_if);
-  extern __shared__ __attribute__((aligned(16))) uint64_t keys[];      // TOPK_SLICES * K keys
-  __shared__ uint64_t best[TOPK_MAXK];
+                                                                        int32_t* __restrict__ classes) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t keys[];      // TOPK_SLICES * K keys + TOPK_SLICES / 2 * K of merge scratch
   const int tid = threadIdx.x, total = TOPK_SLICES * K;
   const uint64_t* src = in_keys + (size_t)blockIdx.x * total;
   for (int i = tid; i < total; i += TOPK_MERGE_THREADS) keys[i] = src[i];
   __syncthreads();
-  merge_sorted_lists(keys, K, best);
+  const uint64_t* best = merge_sorted_lists(keys, keys + total, K);
   for (int j = tid; j < K; j += TOPK_MERGE_THREADS) {
     const uint64_t key = best[j];
     const uint32_t idx = ~(uint32_t)key;
@@ -461,12 +503,51 @@ __global__ __launch_bounds__(TOPK_MERGE_THREADS) void topk_merge_kernel(const ui
   }
 }
 
+// cf_topk_peaks_if_changed: the NMS'd top-K of image blockIdx.x, start to end in ONE workgroup - but only if the map's checksum
+// parts differ from the expected ones (sums[0 .. CK_PARTS) against sums[CK_PARTS .. 2 CK_PARTS)); equal parts: return at once.
+// The decoder's guard for peaks that were computed beside the forward (decode.py): the common case costs one near-empty
+// launch, the rare one (the caller wrote into the heat map between forward and decode) ~0.3 ms - never a wrong result.
+constexpr int CK_PARTS = CF_CHECKSUM_PARTS;
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_fallback_kernel(const float* __restrict__ heat, int C, int H, int W, int K,
+                                                                     uint64_t* __restrict__ keys_ws, float* __restrict__ scores,
+                                                                     int32_t* __restrict__ inds, int32_t* __restrict__ classes,
+                                                                     const unsigned long long* __restrict__ sums) {
+  {
+    int diff = 0;
+    for (int i = threadIdx.x; i < CK_PARTS; i += TOPK_THREADS) diff |= sums[i] != sums[CK_PARTS + i] ? 1 : 0;
+    if (!__syncthreads_or(diff)) return;
+  }
+  extern __shared__ __attribute__((aligned(16))) uint64_t mkeys[];     // merge: TOPK_SLICES * K keys + TOPK_SLICES / 2 * K of scratch
+  const int b = blockIdx.x, tid = threadIdx.x, total = TOPK_SLICES * K;
+  for (int sl = 0; sl < TOPK_SLICES; ++sl) {
+    topk_slice_body<true>(heat, C, H, W, K, keys_ws, b, sl);
+    __syncthreads();                                                   // (the body's LDS is reused by the next slice)
+  }
+  __threadfence_block();                                               // the lists were written by this workgroup's own threads
+  __syncthreads();
+  const uint64_t* src = keys_ws + (size_t)b * total;
+  for (int i = tid; i < total; i += TOPK_THREADS) mkeys[i] = src[i];
+  __syncthreads();
+  const uint64_t* best = merge_sorted_lists(mkeys, mkeys + total, K);
+  const int HW = H * W;
+  for (int j = tid; j < K; j += TOPK_THREADS) {
+    const uint64_t key = best[j];
+    const uint32_t idx = ~(uint32_t)key;
+    const int c = (int)(idx / (uint32_t)HW);
+    scores[(size_t)b * K + j] = u2f((uint32_t)(key >> 32));
+    inds[(size_t)b * K + j] = (int32_t)(idx - (uint32_t)c * HW);
+    classes[(size_t)b * K + j] = c;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Frustum association
 // ---------------------------------------------------------------------------------------------
 constexpr int FR_THREADS = 1024;
 constexpr int FR_SPLIT = 8;         // workgroups per image (pixel shares of the paint pass)
 constexpr int FR_MAXK = 256;
+constexpr int FR_NB = 4;          // boxes of a wave whose ROI loads are in flight together (8: slower - 37 vs 29 us on 40 x 30 boxes, 23 vs 21 on 9 x 7)
 
 __device__ __forceinline__ void py_slice(int start, int stop, int n, int& s, int& e) {
   if (start < 0) {
@@ -504,9 +585,10 @@ __global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
     float* __restrict__ tk_scores, int32_t* __restrict__ tk_inds, int32_t* __restrict__ tk_classes) {
   __shared__ FrBox box[FR_MAXK];
   __shared__ int s_pix[FR_MAXK];               // pixel of peak i
+  __shared__ unsigned long long roi_best[FR_MAXK];   // ROI search: min over the gated returns of (value bits << 32 | position)
   __shared__ short cand[FR_MAXK];              // paint: the boxes that touch this workgroup's rows, last painted first
   __shared__ int s_ncand;
-  extern __shared__ __attribute__((aligned(16))) uint64_t fr_keys[];   // slice_keys: TOPK_SLICES * K keys + K merged
+  extern __shared__ __attribute__((aligned(16))) uint64_t fr_keys[];   // slice_keys: TOPK_SLICES * K keys + TOPK_SLICES / 2 * K of merge scratch
   // FR_SPLIT workgroups per image: each rebuilds the (cheap) box table and paints its share of the
   // pixels - the per-pixel "last covering hit" scan is what takes the time
   const int b = blockIdx.x / FR_SPLIT, part = blockIdx.x % FR_SPLIT;
@@ -521,11 +603,10 @@ __global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
 
   if (slice_keys) {
     const int total = TOPK_SLICES * K;
-    uint64_t* best = fr_keys + total;
     const uint64_t* src = slice_keys + (size_t)b * total;
     for (int i = tid; i < total; i += FR_THREADS) fr_keys[i] = src[i];
     __syncthreads();
-    merge_sorted_lists(fr_keys, K, best);
+    const uint64_t* best = merge_sorted_lists(fr_keys, fr_keys + total, K);
     if (tid < K) {
       const uint64_t key = best[tid];
       const uint32_t idx = ~(uint32_t)key;
@@ -591,45 +672,70 @@ __global__ __launch_bounds__(FR_THREADS) void frustum_kernel(
     bx.found = 0;
     bx.val[0] = bx.val[1] = bx.val[2] = 0.0f;
     box[tid] = bx;
+    roi_best[tid] = ~0ull;
   }
   __syncthreads();
 
-  // ---- nearest gated radar return inside each ROI: one wave per box, row-major first-minimum.  Four positions per lane
-  //      and round in flight; every lane keeps the first minimum of ITS positions (they ascend), the wave then takes the
-  //      smallest value and, among the lanes that hold it, the smallest position: the row-major first occurrence.
-  for (int i = wave; i < K; i += FR_THREADS / 64) {
-    const FrBox bx = box[i];
-    const int rw = bx.roi_x1 - bx.roi_x0, rh = bx.roi_y1 - bx.roi_y0;
-    if (rw <= 0 || rh <= 0) continue;
-    const int n = rw * rh;
-    float best = INFINITY;
-    int best_pos = 0x7fffffff;
-    for (int base = 0; base < n; base += 256) {
-      float v[4];
+  // ---- nearest gated radar return inside each ROI, row-major first-minimum.  A wave takes FR_NB of its boxes at a time (box
+  //      i = g0 + 16 k) and walks their ROIs in rounds of 256 positions each: 4 FR_NB independent loads per lane and round.  The
+  //      minimum is taken by ONE LDS atomic per lane and box on a 64-bit key (value bits << 32 | position): gated values are
+  //      positive, so their bits order like the values, and among equal values the smallest position - the row-major first
+  //      occurrence - wins.  No wave reduction (12 dependent cross-lane steps per box were 10 of this kernel's 32 us).
+  constexpr int FR_WAVES = FR_THREADS / 64;
+  for (int g0 = wave; g0 < K; g0 += FR_NB * FR_WAVES) {
+    int rw[FR_NB], n[FR_NB], y0[FR_NB], x0[FR_NB];
+    unsigned magic[FR_NB];                                       // ceil(2^32 / rw): q / rw == umulhi(q, magic) for q < 2^32 / rw (q < 2^16 here)
+    float gl[FR_NB], gh[FR_NB];
+    unsigned long long best[FR_NB];
+    int n_max = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int q = base + lane + 64 * j;
-        const int qq = q < n ? q : 0;
-        v[j] = pc[(bx.roi_y0 + qq / rw) * W + bx.roi_x0 + qq % rw];
-        if (q >= n) v[j] = 0.0f;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (v[j] != 0.0f && v[j] < bx.hi && v[j] > bx.lo && v[j] < best) {
-          best = v[j];
-          best_pos = base + lane + 64 * j;
-        }
+    for (int k = 0; k < FR_NB; ++k) {
+      const int i = g0 + k * FR_WAVES;
+      const FrBox& bx = box[i < K ? i : g0];
+      const int w_ = bx.roi_x1 - bx.roi_x0, h_ = bx.roi_y1 - bx.roi_y0;
+      rw[k] = w_ > 1 ? w_ : 1;
+      magic[k] = rw[k] > 1 ? (unsigned)((0x100000000ull + (unsigned)rw[k] - 1) / (unsigned)rw[k]) : 0u;
+      n[k] = (i < K && w_ > 0 && h_ > 0) ? w_ * h_ : 0;
+      y0[k] = bx.roi_y0; x0[k] = bx.roi_x0; gl[k] = bx.lo; gh[k] = bx.hi;
+      best[k] = ~0ull;
+      n_max = max(n_max, n[k]);
     }
-    float mn = best;
-    for (int off = 32; off > 0; off >>= 1) mn = fminf(mn, __shfl_xor(mn, off));
-    int pos = (best == mn && mn < INFINITY) ? best_pos : 0x7fffffff;
-    for (int off = 32; off > 0; off >>= 1) pos = min(pos, __shfl_xor(pos, off));
-    if (lane == 0 && pos != 0x7fffffff) {
-      const int yy = bx.roi_y0 + pos / rw, xx = bx.roi_x0 + pos % rw;
-      box[i].found = 1;
-      box[i].val[0] = mn / max_pc_dist;
-      box[i].val[1] = pc[HW + yy * W + xx];
-      box[i].val[2] = pc[2 * HW + yy * W + xx];
+    for (int base = 0; base < n_max; base += 256) {
+      float v[FR_NB][4];
+#pragma unroll
+      for (int k = 0; k < FR_NB; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = base + lane + 64 * j;
+          const int qq = q < n[k] ? q : 0;
+          const int qr = rw[k] > 1 ? (int)__umulhi((unsigned)qq, magic[k]) : qq;       // qq / rw
+          const float t = pc[(y0[k] + qr) * W + x0[k] + (qq - qr * rw[k])];          // (n[k] == 0: position 0 of a valid ROI origin or of box g0)
+          v[k][j] = q < n[k] ? t : 0.0f;
+        }
+#pragma unroll
+      for (int k = 0; k < FR_NB; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (v[k][j] != 0.0f && v[k][j] < gh[k] && v[k][j] > gl[k]) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(v[k][j]) << 32) | (unsigned)(base + lane + 64 * j);
+            best[k] = key < best[k] ? key : best[k];
+          }
+    }
+#pragma unroll
+    for (int k = 0; k < FR_NB; ++k)
+      if (best[k] != ~0ull) atomicMin(&roi_best[g0 + k * FR_WAVES], best[k]);
+  }
+  __syncthreads();
+  if (tid < K) {
+    const unsigned long long key = roi_best[tid];
+    if (key != ~0ull) {
+      const FrBox& bx = box[tid];
+      const int rw_ = bx.roi_x1 - bx.roi_x0, pos = (int)(unsigned)key;
+      const int yy = bx.roi_y0 + pos / rw_, xx = bx.roi_x0 + pos % rw_;
+      box[tid].found = 1;
+      box[tid].val[0] = __uint_as_float((unsigned)(key >> 32)) / max_pc_dist;
+      box[tid].val[1] = pc[HW + yy * W + xx];
+      box[tid].val[2] = pc[2 * HW + yy * W + xx];
     }
   }
   __syncthreads();
@@ -1216,38 +1322,47 @@ extern "C" size_t cf_topk_workspace_bytes_nms(int B, int C, int H, int W, int K)
 
 namespace {
 
-// position-weighted 64-bit checksum of a buffer of 32-bit words: sum of word[i] * (odd 32-bit weight of i) mod 2^64 - exact
-// integer arithmetic, independent of the order of summation, sensitive to WHERE a value sits (a plain sum is blind to swaps)
-__global__ __launch_bounds__(256) void checksum64_kernel(const uint32_t* __restrict__ x, long n, unsigned long long* __restrict__ out) {
+// position-weighted 64-bit checksum of a buffer of 32-bit words, as CK_PARTS partial sums: part[b] = sum over the words block b
+// walks (16-byte groups g = b * 1024 + t, + CK_PARTS * 1024, ...) of word[i] * (odd 32-bit weight of i) mod 2^64 - exact integer
+// arithmetic, a fixed partition, so two runs over the same bits give the same parts; sensitive to WHERE a value sits (a plain
+// sum is blind to swaps).  No atomics, no zeroing: 4,096 same-address atomics took 50 us, the memset was a launch of its own.
+__global__ __launch_bounds__(1024) void checksum64_kernel(const uint32_t* __restrict__ x, long n, unsigned long long* __restrict__ parts) {
   unsigned long long acc = 0ull;
-  const long step = (long)gridDim.x * 256;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += step)
+  const long step = (long)CK_PARTS * 1024;
+  const long n4 = (reinterpret_cast<uintptr_t>(x) & 15) == 0 ? n / 4 : 0;           // 16-byte loads over the aligned body
+  const u32x4p* x4 = reinterpret_cast<const u32x4p*>(x);
+  for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < n4; i += step) {
+    const u32x4p v = x4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      acc += (unsigned long long)v[e] * (unsigned long long)(((uint32_t)(4 * i + e) * 2654435761u) | 1u);
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * 1024 + threadIdx.x; i < n; i += step)
     acc += (unsigned long long)x[i] * (unsigned long long)(((uint32_t)i * 2654435761u) | 1u);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += (unsigned long long)__shfl_xor((long long)acc, o, 64);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+  __shared__ unsigned long long part[16];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0ull;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    parts[blockIdx.x] = t;
+  }
 }
 
 }  // namespace
 
-extern "C" int cf_checksum64(const void* x, long n_words, unsigned long long* out, void* stream) {
-  CF_REQUIRE(x && out && n_words >= 0, "cf_checksum64: null buffer or n_words=%ld", n_words);
-  hipStream_t st = (hipStream_t)stream;
-  if (const hipError_t e = hipMemsetAsync(out, 0, sizeof(unsigned long long), st); e != hipSuccess) {
-    cf_set_error("cf_checksum64: hipMemsetAsync failed: %s", hipGetErrorString(e));
-    return CF_ELAUNCH;
-  }
-  if (n_words == 0) return CF_OK;
-  const long blocks = (n_words + 1023) / 1024;
-  hipLaunchKernelGGL(checksum64_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st,
-                     static_cast<const uint32_t*>(x), n_words, out);
+extern "C" int cf_checksum64(const void* x, long n_words, unsigned long long* parts, void* stream) {
+  CF_REQUIRE(x && parts && n_words >= 0, "cf_checksum64: null buffer or n_words=%ld", n_words);
+  hipLaunchKernelGGL(checksum64_kernel, dim3(CK_PARTS), dim3(1024), 0, (hipStream_t)stream, static_cast<const uint32_t*>(x), n_words, parts);
   return cf_check_launch("cf_checksum64");
 }
 
 namespace {
 
 int topk_peaks_impl(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
-                    int32_t* inds, int32_t* classes, void* workspace, const unsigned long long* only_if, void* stream) {
+                    int32_t* inds, int32_t* classes, void* workspace, void* stream) {
   CF_REQUIRE(heat && scores && inds && classes && workspace, "cf_topk_peaks: null buffer");
   CF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cf_topk_peaks: bad geometry");
   CF_REQUIRE(K >= 1 && K <= TOPK_MAXK, "cf_topk_peaks: K=%d outside [1,%d]", K, TOPK_MAXK);
@@ -1256,26 +1371,30 @@ int topk_peaks_impl(const float* heat, int B, int C, int H, int W, int K, int nm
   hipStream_t st = (hipStream_t)stream;
   uint64_t* keys = static_cast<uint64_t*>(workspace);
   CF_REQUIRE(nms >= 0 && nms <= 2, "cf_topk_peaks: nms=%d", nms);
+  const bool two_pass = nms == 2;
   if (nms == 2) {   // suppressed map first (scratch behind the keys), then the plain top-K over it
     float* sup = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + ((cf_topk_workspace_bytes(B, K) + 255) / 256) * 256);
     const long total = (long)B * C * H * W;
     const long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(nms_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, heat, sup, H, W, total, only_if);
+    hipLaunchKernelGGL(nms_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st, heat, sup, H, W, total);
     heat = sup;
     nms = 0;
   }
   static const int reg_off = [] { const char* e = getenv("CF_TOPK_REG"); return e ? atoi(e) == 0 : 0; }();   // (dev A/B: CF_TOPK_REG=0 = the 256-thread kernel)
   const long slice_len = ((long)C * H * W + TOPK_SLICES - 1) / TOPK_SLICES;
   if (nms)
-    hipLaunchKernelGGL(topk_slice_kernel<true>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys, only_if);
-  else if (slice_len <= (long)TOPK_RT * TOPK_RE && !reg_off)
-    hipLaunchKernelGGL(topk_slice_reg_kernel, dim3(B * TOPK_SLICES), dim3(TOPK_RT), 0, st, heat, C, H, W, K, keys, only_if);
+    hipLaunchKernelGGL(topk_slice_kernel<true>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys);
+  // (the register-cached kernel - 1024 threads and 35 KB of LDS per workgroup - for the plain top-K, which sits alone on the chip
+  //  between the two head launches; behind the NMS pass - the decoder's top-K, issued BESIDE the secondary head launch - the
+  //  256-thread kernel, whose workgroups find room next to the head workgroups: the big ones waited for the whole launch)
+  else if (slice_len <= (long)TOPK_RT * TOPK_RE && !reg_off && !two_pass)
+    hipLaunchKernelGGL(topk_slice_reg_kernel, dim3(B * TOPK_SLICES), dim3(TOPK_RT), 0, st, heat, C, H, W, K, keys);
   else
-    hipLaunchKernelGGL(topk_slice_kernel<false>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys, only_if);
-  const size_t merge_lds = (size_t)TOPK_SLICES * K * sizeof(uint64_t);
+    hipLaunchKernelGGL(topk_slice_kernel<false>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys);
+  const size_t merge_lds = (size_t)(TOPK_SLICES + TOPK_SLICES / 2) * K * sizeof(uint64_t);
   static CfLdsLimit merge_limit;
   merge_limit.ensure(topk_merge_kernel, merge_lds, 65536);
-  hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(TOPK_MERGE_THREADS), merge_lds, st, keys, K, H * W, scores, inds, classes, only_if);
+  hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(TOPK_MERGE_THREADS), merge_lds, st, keys, K, H * W, scores, inds, classes);
   return cf_check_launch("cf_topk_peaks");
 }
 
@@ -1283,14 +1402,23 @@ int topk_peaks_impl(const float* heat, int B, int C, int H, int W, int K, int nm
 
 extern "C" int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
                              int32_t* inds, int32_t* classes, void* workspace, void* stream) {
-  return topk_peaks_impl(heat, B, C, H, W, K, nms, scores, inds, classes, workspace, nullptr, stream);
+  return topk_peaks_impl(heat, B, C, H, W, K, nms, scores, inds, classes, workspace, stream);
 }
 
 extern "C" int cf_topk_peaks_if_changed(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,
                                         int32_t* inds, int32_t* classes, void* workspace,
                                         const unsigned long long* sums, void* stream) {
-  CF_REQUIRE(sums != nullptr, "cf_topk_peaks_if_changed: null checksum pair");
-  return topk_peaks_impl(heat, B, C, H, W, K, nms, scores, inds, classes, workspace, sums, stream);
+  CF_REQUIRE(heat && scores && inds && classes && workspace && sums, "cf_topk_peaks_if_changed: null buffer");
+  CF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "cf_topk_peaks_if_changed: bad geometry");
+  CF_REQUIRE(K >= 1 && K <= TOPK_MAXK, "cf_topk_peaks_if_changed: K=%d outside [1,%d]", K, TOPK_MAXK);
+  CF_REQUIRE((long)C * H * W >= K && (long)C * H * W < (1L << 31), "cf_topk_peaks_if_changed: image of %ld elements", (long)C * H * W);
+  CF_REQUIRE(nms == 1 || nms == 2, "cf_topk_peaks_if_changed: nms=%d (the guard of the decoder's NMS'd peaks: 1 or 2, same result)", nms);
+  const size_t lds = (size_t)(TOPK_SLICES + TOPK_SLICES / 2) * K * sizeof(uint64_t);
+  static CfLdsLimit limit;
+  limit.ensure(topk_fallback_kernel, lds, 65536);
+  hipLaunchKernelGGL(topk_fallback_kernel, dim3(B), dim3(TOPK_THREADS), lds, (hipStream_t)stream, heat, C, H, W, K,
+                     static_cast<uint64_t*>(workspace), scores, inds, classes, sums);
+  return cf_check_launch("cf_topk_peaks_if_changed");
 }
 
 extern "C" int cf_frustum_assoc(const int32_t* inds, int K, const float* depth, const float* wh,
@@ -1322,12 +1450,12 @@ extern "C" int cf_topk_frustum(const float* heat, int C, int K, const float* dep
   static const int reg_off = [] { const char* e = getenv("CF_TOPK_REG"); return e ? atoi(e) == 0 : 0; }();
   const long slice_len = ((long)C * H * W + TOPK_SLICES - 1) / TOPK_SLICES;
   if (slice_len <= (long)TOPK_RT * TOPK_RE && !reg_off)
-    hipLaunchKernelGGL(topk_slice_reg_kernel, dim3(B * TOPK_SLICES), dim3(TOPK_RT), 0, st, heat, C, H, W, K, keys,
-                       (const unsigned long long*)nullptr);
+    hipLaunchKernelGGL(topk_slice_reg_kernel, dim3(B * TOPK_SLICES), dim3(TOPK_RT), 0, st, heat, C, H, W, K, keys);
   else
-    hipLaunchKernelGGL(topk_slice_kernel<false>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys,
-                       (const unsigned long long*)nullptr);
-  const size_t lds = ((size_t)TOPK_SLICES * K + K) * sizeof(uint64_t);
+    hipLaunchKernelGGL(topk_slice_kernel<false>, dim3(B * TOPK_SLICES), dim3(TOPK_THREADS), 0, st, heat, C, H, W, K, keys);
+  const size_t lds = (size_t)(TOPK_SLICES + TOPK_SLICES / 2) * K * sizeof(uint64_t);     // <= 48 KB at K = 256, + 17 KB static
+  static CfLdsLimit fr_limit;
+  fr_limit.ensure(frustum_kernel, lds, 65536);
   hipLaunchKernelGGL(frustum_kernel, dim3(B * FR_SPLIT), dim3(FR_THREADS), lds, st, (const int32_t*)nullptr, K, depth, wh, dim,
                      rot, calib, pc_dep, H, W, max_pc_dist, pc_hm, pc_hm_nhwc4, static_cast<unsigned*>(pc_hm_split8),
                      (const uint64_t*)keys, scores, inds, classes);

@@ -29,15 +29,16 @@ def _peaks_and_maps(outputs, K):
     _, _, H, W = heat.shape
     # The forward may have computed exactly these peaks already, beside its own launches (model._Plan.run: the heat map tensor
     # carries them with a checksum of the bits they were computed from).  They are used only for the very tensor object, and
-    # only while its contents still have that checksum: the map is summed again here and the top-k launches that follow
-    # compare the two sums ON THE DEVICE - equal: they return at once and the carried peaks stand; different (an in-place
-    # write, also one through `heat.data`, which bumps no version counter): they recompute into the same buffers.  The
-    # reference's fusionDecode always reads the map it is given (model/decode.py:38-57); so does this, at ~10 us instead of 75.
+    # only while its contents still have that checksum: the map is summed again here and the guard launch that follows
+    # compares the two sets of partial sums ON THE DEVICE - equal: it returns at once and the carried peaks stand; different (an
+    # in-place write, also one through `heat.data`, which bumps no version counter): it recomputes them into the same buffers.
+    # The reference's fusionDecode always reads the map it is given (model/decode.py:38-57); so does this, in two short launches
+    # instead of the three of the NMS + top-k.
     cached = getattr(heat, "_cf_peaks", None)
     if cached is not None and cached[0] == K and cached[1] == heat.data_ptr() and heat.is_contiguous() \
             and not torch.cuda.is_current_stream_capturing():
         pk_s, pk_i, pk_c, sums = cached[2:]
-        ops.checksum64(heat, out=sums[1:])
+        ops.checksum64(heat, out=sums[ops.CHECKSUM_PARTS:])
         scores, inds, classes = ops.topk_peaks(heat, K, nms=True, out=(pk_s, pk_i, pk_c), only_if_changed=sums)
     else:
         scores, inds, classes = ops.topk_peaks(heat, K, nms=True)

@@ -601,9 +601,8 @@ class _Plan:
         # top-k passes take: DESIGN.md section 9.)
         self.peaks_step = None
         split = fuse_all and bool(model.heads_lanes) and primary[0] == "heatmap"
-        if split:
-            self.use_lanes = True
-            fused_heads("tails.primary", primary, [feat_in], [64])
+        def peaks_lane():
+            """the side lane: starts behind whatever the caller's stream has issued so far, runs the decoder's NMS + top-k"""
             ev_a = self.new_event()
             self.ctl("rec", 0, ev_a)
             self.lane = 1
@@ -613,6 +612,14 @@ class _Plan:
             self.ev_peaks = self.new_event()
             self.ctl("rec", 1, self.ev_peaks)
             self.lane = 0
+
+        if split:
+            self.use_lanes = True
+            fused_heads("tails.primary", primary, [feat_in], [64])
+            # radar: the lane starts behind the frustum chain (below), not behind the primary launch - its chip-wide NMS pass
+            # beside the chain's slice top-k tripled that kernel's time (41 vs 14 us) on the one path everything waits for
+            if not (radar and model.peaks_behind_frustum):
+                peaks_lane()
         elif fuse_all:
             fused_heads("tails.primary", primary, [feat_in], [64])
         elif bf:
@@ -634,6 +641,8 @@ class _Plan:
                 self.topk_step = len(self.steps); self.add_step(None)
             self.frustum_step = len(self.steps); self.add_step(None)
             ss = 256 * len(SECONDARY_HEADS)
+            if split and self.peaks_step is None:
+                peaks_lane()
             if fuse_all:
                 fused_heads("tails.secondary", SECONDARY_HEADS, [feat_in, self.pc_hm8], [64, 8])
                 if split:
@@ -761,7 +770,7 @@ class _Plan:
                 pk_s = torch.empty((B, self.K), device=dev, dtype=torch.float32)
                 pk_i = torch.empty((B, self.K), device=dev, dtype=torch.int32)
                 pk_c = torch.empty((B, self.K), device=dev, dtype=torch.int32)
-                pk_sum = torch.empty(2, device=dev, dtype=torch.int64)     # [checksum of the map the peaks belong to, decode's re-check]
+                pk_sum = torch.empty(2 * ops.CHECKSUM_PARTS, device=dev, dtype=torch.int64)   # checksum parts of the map the peaks belong to | decode's re-check
                 n_words = B * heads["heatmap"] * h4 * w4
                 self.steps[self.peaks_step] = (_peaks_and_checksum, lib, (y["heatmap"].data_ptr(), B, heads["heatmap"], h4, w4, self.K, 2,
                                                pk_s.data_ptr(), pk_i.data_ptr(), pk_c.data_ptr(), self.pk_ws.data_ptr()),
@@ -883,6 +892,8 @@ class DLASeg(nn.Module):
                                           # in the two-stream step the two launches are 0.024 ms faster (round 5, 6 of 6 A/B pairs)
         self.heads_lanes = True  # fused heads: the decoder's NMS + top-k on a side stream beside the frustum path and the secondary
                                  # launch (_Plan heads section), handed to decode.py with the heat map
+        self.peaks_behind_frustum = True  # heads_lanes on a radar model: the decoder's lane starts behind the frustum chain instead of
+                                          # behind the primary head launch (False: round 5's order; same results)
         self.frustum_fused = True  # radar: top-k of the raw heat map + frustum association as cf_topk_frustum (2 launches, the merge in the
                                    # association kernel's prologue) instead of cf_topk_peaks + cf_frustum_assoc (3); same bits
         self.proj_fuse = True    # the sub-tree that opens a level: `project` of the pooled input as k-steps of tree1.conv2

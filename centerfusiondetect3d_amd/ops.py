@@ -517,15 +517,19 @@ def nhwc_to_nchw(x, channels=None, out=None):
     return out
 
 
+CHECKSUM_PARTS = 256     # CF_CHECKSUM_PARTS of include/cf_hip.h
+
+
 def checksum64(t, out=None):
-    """Position-weighted 64-bit checksum of a contiguous device tensor's bits (cf_checksum64) -> 1-element int64 device tensor;
-    no host sync."""
+    """Position-weighted 64-bit checksum of a contiguous device tensor's bits (cf_checksum64) as CHECKSUM_PARTS partial sums
+    over a fixed partition of its words -> (256,) int64 device tensor: equal bits <=> equal parts.  No host sync."""
     _need_cuda(t)
     nbytes = t.numel() * t.element_size()
     if not t.is_contiguous() or nbytes % 4:
         raise _lib.CfHipError("checksum64: contiguous tensor of a multiple of 4 bytes")
     if out is None:
-        out = torch.empty(1, device=t.device, dtype=torch.int64)
+        out = torch.empty(CHECKSUM_PARTS, device=t.device, dtype=torch.int64)
+    assert out.numel() == CHECKSUM_PARTS and out.dtype == torch.int64 and out.is_contiguous()
     _lib.check(_lib.load().cf_checksum64(t.data_ptr(), nbytes // 4, out.data_ptr(), _lib.stream_ptr()), "cf_checksum64")
     return out
 
@@ -533,8 +537,9 @@ def checksum64(t, out=None):
 def topk_peaks(heat, K=100, nms=False, out=None, only_if_changed=None):
     """(B,C,H,W) NCHW scores -> scores (B,K) f32, inds (B,K) i32, classes (B,K) i32.
     nms: False / True (3x3 equality NMS first; True = the two-pass form, 1 = suppress on the fly).
-    out: (scores, inds, classes) to write into; only_if_changed: a 2-element int64 device tensor - the launches do nothing
-    when its two words are equal (cf_topk_peaks_if_changed: `out` then keeps what it held)."""
+    out: (scores, inds, classes) to write into; only_if_changed: a (2 * CHECKSUM_PARTS,) int64 device tensor [expected parts |
+    actual parts] - the launch does nothing when they are equal (cf_topk_peaks_if_changed: `out` then keeps what it held) and
+    computes the NMS'd peaks otherwise (one workgroup per image: the rare path)."""
     _need_cuda(heat)
     if not heat.is_contiguous():
         heat = heat.contiguous()

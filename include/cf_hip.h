@@ -382,14 +382,18 @@ size_t cf_topk_workspace_bytes(int B, int K);
  * parallel pass into scratch memory behind the keys - workspace must then hold
  * cf_topk_workspace_bytes_nms(B, C, H, W, K) bytes.  (nms == 1 suppresses on the fly, no scratch.) */
 size_t cf_topk_workspace_bytes_nms(int B, int C, int H, int W, int K);
-/* (ABI 6) cf_checksum64: out[0] = sum over i < n_words of word[i] * w(i) mod 2^64, w(i) = ((uint32)i * 2654435761) | 1 - a
- * position-weighted checksum of a device buffer read as 32-bit words (exact integer arithmetic; `out` is zeroed by the call).
- * cf_topk_peaks_if_changed: cf_topk_peaks that does NOTHING when sums[0] == sums[1] (two checksums in device memory, tested
- * on the device: no host sync) and recomputes scores / inds / classes otherwise.  Together they let the host keep the peaks
- * the forward computed beside its own launches (model.py: heads_lanes) and still honour ANY later change of the heat map -
- * also one made through `tensor.data`, which no version counter sees - as the reference's fusionDecode would
- * (model/decode.py:38-57: it always reads the map it is given).  No reference counterpart. */
-int cf_checksum64(const void* x, long n_words, unsigned long long* out, void* stream);
+/* (ABI 6) cf_checksum64: a position-weighted checksum of a device buffer read as 32-bit words, as CF_CHECKSUM_PARTS partial sums
+ * over a fixed partition of the words: parts[b] = sum of word[i] * w(i) mod 2^64, w(i) = ((uint32)i * 2654435761) | 1 (exact
+ * integer arithmetic: the same bits give the same parts; one launch, no atomics, nothing to zero).
+ * cf_topk_peaks_if_changed: the guard of peaks computed earlier - sums = [expected parts | actual parts] (2 x
+ * CF_CHECKSUM_PARTS words in device memory, compared ON THE DEVICE: no host sync).  All equal: the launch does nothing and
+ * scores / inds / classes keep what they hold.  Any part differs: it computes cf_topk_peaks(heat, nms) into them - one
+ * workgroup per image, ~0.3 ms: the rare path.  nms = 1 or 2 (same result); workspace: cf_topk_workspace_bytes(B, K) bytes.
+ * Together they let the host keep the peaks the forward computed beside its own launches (model.py: heads_lanes) and still
+ * honour ANY later change of the heat map - also one made through `tensor.data`, which no version counter sees - as the
+ * reference's fusionDecode would (model/decode.py:38-57: it always reads the map it is given).  No reference counterpart. */
+#define CF_CHECKSUM_PARTS 256
+int cf_checksum64(const void* x, long n_words, unsigned long long* parts, void* stream);
 int cf_topk_peaks_if_changed(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores, int32_t* inds,
                              int32_t* classes, void* workspace, const unsigned long long* sums, void* stream);
 int cf_topk_peaks(const float* heat, int B, int C, int H, int W, int K, int nms, float* scores,

@@ -286,7 +286,7 @@ def test_decoder_peaks_travel_with_the_heat_map(dev):
     assert K == 100 and ptr == hm.data_ptr()
     s_r, i_r, c_r = ops.topk_peaks(hm, K, nms=True)
     assert torch.equal(s_c, s_r) and torch.equal(i_c, i_r) and torch.equal(c_c, c_r)
-    assert int(sums[0]) == int(ops.checksum64(hm)[0]) != 0
+    assert sums.shape == (2 * ops.CHECKSUM_PARTS,) and torch.equal(sums[:ops.CHECKSUM_PARTS], ops.checksum64(hm)) and int(sums[0]) != 0
     det_plain = fresh(out[0])
     det_cached, _ = decode_packed([dict(out[0])], (H // 4, W // 4), K=K)
     assert torch.equal(det_cached, det_plain)
