@@ -576,6 +576,8 @@ def main():
                     help="A/B: the level-2 Tree's max-pool as its own launch instead of a second output of the stem (model.stem_pool)")
     ap.add_argument("--no-heads-lanes", action="store_true",
                     help="A/B: the decoder's NMS + top-k behind the forward on the caller's stream instead of beside the secondary heads (model.heads_lanes = False)")
+    ap.add_argument("--no-trunk-on-caller", action="store_true",
+                    help="A/B: every trunk sub-batch on a side stream (round 5) instead of the last one on the caller's stream (model.trunk_on_caller = False)")
     ap.add_argument("--peaks-behind-primary", action="store_true",
                     help="A/B: the decoder's top-k lane starts behind the primary head launch (round 5) instead of behind the frustum chain")
     ap.add_argument("--no-frustum-fused", action="store_true",
@@ -661,6 +663,8 @@ def main():
         model.frustum_fused = False
     if args.peaks_behind_primary:
         model.peaks_behind_frustum = False
+    if args.no_trunk_on_caller:
+        model.trunk_on_caller = False
     if args.lanes_max_frames is not None:
         model.lanes_max_frames = args.lanes_max_frames
     if args.no_heads_lanes:

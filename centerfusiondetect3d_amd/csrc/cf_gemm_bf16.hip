@@ -45,6 +45,7 @@ __device__ __forceinline__ float act_f(float v, int act) {
   return v;
 }
 
+#ifdef CF_LEGACY_HEADS   // (the unfused heads' bf16x3 convolution of rounds 1-2: nothing dispatches it in the default build)
 // BK = K depth staged per main-loop step (32 or 64 bf16).  LDS rows are BK*2 + 16 bytes per plane:
 // an odd number of 16-byte slots, so the 16 rows a ds_read_b128 lane group touches never collide.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
@@ -227,6 +228,8 @@ __global__ __launch_bounds__(256) void conv_bf16x3_kernel(ConvB p) {
   }
 }
 
+#endif  // CF_LEGACY_HEADS
+
 // fp32 NHWC [M][C] -> split-bf16 [M][2][Cs] (Cs >= C, channels C..Cs-1 zero), 8 channels per thread
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, unsigned char* __restrict__ out,
                                                          long M, int C, int in_stride, int Cs) {
@@ -255,6 +258,13 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 
 extern "C" int cf_conv2d_bf16x3(const cf_conv_args* a, void* stream) {
   CF_REQUIRE(a != nullptr, "cf_conv2d_bf16x3: null args");
+#ifndef CF_LEGACY_HEADS
+  // the unfused heads' convolution (rounds 1-2): the fused head launches (cf_head_fused) carry every bf16x3 layer of the path now
+  (void)stream;
+  CF_REQUIRE(false, "cf_conv2d_bf16x3 is a legacy kernel path: rebuild libcfhip with -DCF_LEGACY_HEADS (CF_EXTRA_FLAGS); the heads "
+                    "run on cf_head_fused, fp32-accurate convolutions on cf_conv2d_f16x3 / cf_conv2d_fused");
+  return CF_EINVAL;
+#else
   CF_REQUIRE(a->n_src >= 1 && a->n_src <= CF_MAX_SRC, "cf_conv2d_bf16x3: n_src=%d", a->n_src);
   CF_REQUIRE(a->K_pad > 0 && a->K_pad % 32 == 0, "cf_conv2d_bf16x3: K_pad=%d not a multiple of 32", a->K_pad);
   CF_REQUIRE(a->N_pad >= a->N && a->N_pad % 32 == 0 && a->N > 0, "cf_conv2d_bf16x3: N=%d N_pad=%d", a->N, a->N_pad);
@@ -314,6 +324,7 @@ extern "C" int cf_conv2d_bf16x3(const cf_conv_args* a, void* stream) {
     hipLaunchKernelGGL((conv_bf16x3_kernel<128, 32, 4, 1, 32>), dim3(MT * k.NT), dim3(256), 0, st, k);
   }
   return cf_check_launch("cf_conv2d_bf16x3");
+#endif
 }
 
 extern "C" int cf_split_bf16(const float* x, void* out, long M, int C, int in_stride, int Cs, void* stream) {

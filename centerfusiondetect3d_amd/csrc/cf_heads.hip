@@ -67,6 +67,7 @@ __device__ __forceinline__ const bf16x8* wfrag(const unsigned char* w, int rt, i
 
 // accumulator (lane = pixel ct*32+li, reg r = channel 64w + 32rt + (r&3) + 8(r>>2) + 4h) -> ReLU(acc + b)
 // -> split bf16 -> LDS tile [plane][px][528 B]
+#ifdef CF_LEGACY_HEADS   // (32x32x16 / slot-table head kernels of rounds 1-3: nothing dispatches them in the default build)
 __device__ __forceinline__ void store_hidden_tile(unsigned char* xt, const f32x16 (&acc)[2][2], const float* bias,
                                                   int wave, int li, int h) {
 #pragma unroll
@@ -93,6 +94,8 @@ __device__ __forceinline__ void store_hidden_tile(unsigned char* xt, const f32x1
 
 // the same from 16x16 accumulators (v_mfma_f32_16x16x32_bf16: lane = pixel ct*16 + (l & 15), reg r = channel
 // 64w + 16rt + 4(l >> 4) + r) of one 64-pixel half tile
+#endif  // CF_LEGACY_HEADS
+
 template <bool SCALED = false>
 __device__ __forceinline__ void store_hidden_tile16(unsigned char* xt, const f32x4 (&acc)[4][4], const float* bias,
                                                     int wave, int lane, float sc = 1.0f, int pxcol = -1) {
@@ -141,6 +144,7 @@ struct TileMap {       // 64 pixels of a tile at (y0, x0) of image b: 4 rows of 
 };
 
 // 4 per-wave partial output tiles [32 n][64 px] -> LDS -> sum + bias + activation -> NCHW
+#ifdef CF_LEGACY_HEADS   // (32x32x16 / slot-table head kernels of rounds 1-3: nothing dispatches them in the default build)
 template <class PixMap>
 __device__ __forceinline__ void reduce_and_store(const HeadTailK& p, unsigned char* xt, const f32x16 (&oacc)[2],
                                                  int head, const PixMap& pm) {
@@ -261,6 +265,8 @@ __device__ __forceinline__ void head_tail_from_lds(const HeadTailK& p, unsigned 
 
 // The same chain on v_mfma_f32_16x16x32_bf16 (weights packed by pack_fragments16: w_hidden [16 rt][8 ks], w_out one
 // 16-row tile): wave w owns channels [64w, 64w+64) x 64 pixels as 4 x 4 accumulators of 16 x 16; a k-step is 32 deep.
+#endif  // CF_LEGACY_HEADS
+
 template <class PixMap>
 __device__ __forceinline__ void head_tail_from_lds16(const HeadTailK& p, unsigned char* xt, int head, const PixMap& pm) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -372,6 +378,7 @@ __device__ __forceinline__ void head_tail_from_lds16(const HeadTailK& p, unsigne
   }
 }
 
+#ifdef CF_LEGACY_HEADS   // (32x32x16 / slot-table head kernels of rounds 1-3: nothing dispatches them in the default build)
 // Tail only: the 256-channel hidden tile comes from a split-bf16 tensor in HBM.
 __global__ __launch_bounds__(256) void head_tail_kernel(HeadTailK p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xt[];  // [2 planes][64 px][528 B]
@@ -438,6 +445,7 @@ __global__ __launch_bounds__(256) void head_tail_kernel(HeadTailK p) {
   }
   reduce_and_store(p, xt, oacc, head, FlatMap{m0, p.M, p.HW});
 }
+#endif  // CF_LEGACY_HEADS
 
 // ---------------------------------------------------------------------------------------------
 // Whole head in one launch: 3x3 conv (64 [+3] -> 256) + ReLU, then the tail above.  The first layer
@@ -462,6 +470,7 @@ constexpr int HF_BUF = 2 * HF_PLANE;              // 10240 per chunk buffer
 constexpr int HF_MAX_CHUNKS = 64;
 constexpr int HF_LDS = HT_LDS + HF_MAX_CHUNKS * 4 * (int)sizeof(cf_slot);   // tile area + slot table
 
+#ifdef CF_LEGACY_HEADS   // (the slot-table head kernel)
 __global__ __launch_bounds__(256) void head_fused_kernel(HeadFusedK q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char xt[];  // B chunk buffers, later the hidden tile
   const HeadTailK& p = q.t;
@@ -594,6 +603,8 @@ __global__ __launch_bounds__(256) void head_fused_kernel(HeadFusedK q) {
 }
 
 
+#endif  // CF_LEGACY_HEADS
+
 // ---------------------------------------------------------------------------------------------
 // Whole head with n_hidden == 0 on a 2-D PATCH: one workgroup owns an 8 x 16 pixel tile (128 px) of
 // one image and one head.  The (8+2) x (16+2) input patch - all 64 feature channels (and the 8-channel
@@ -629,6 +640,7 @@ struct HeadPatchK {
   float first_scale[CF_MAX_HEADS];           // MX kernel: 2^-(s+4) of head i's first layer
 };
 
+#ifdef CF_LEGACY_HEADS   // (32x32x16 / slot-table head kernels of rounds 1-3: nothing dispatches them in the default build)
 template <int NS, bool PC>
 __global__ __launch_bounds__(256, 2) void head_patch_kernel(HeadPatchK q) {
   constexpr int ROWB = NS * 64 + (PC ? 32 : 0) + 16;     // odd multiple of 16 B
@@ -851,6 +863,8 @@ __global__ __launch_bounds__(256, 2) void head_patch_kernel(HeadPatchK q) {
   }
 }
 
+
+#endif  // CF_LEGACY_HEADS
 
 // ---------------------------------------------------------------------------------------------
 // The same whole-head patch kernel on v_mfma_f32_16x16x32_bf16.  Under the chip's power management a dense MFMA
@@ -1379,15 +1393,29 @@ static int fill_tail(const cf_head_tail_args* a, HeadTailK& k, const char* who, 
   return CF_OK;
 }
 
+// Kernels of rounds 1-3 that no default or switchable path of the host dispatches any more - the stand-alone tail
+// (cf_head_tail), the slot-table fused head and the 32x32x16 patch kernel (cf_head_fused without mfma16 / layout3x3) - are
+// compiled only with -DCF_LEGACY_HEADS (build.py never sets it): the default library answers those calls with CF_EINVAL.
+#ifndef CF_LEGACY_HEADS
+#define CF_LEGACY_ONLY(what) CF_REQUIRE(false, "%s is a legacy kernel path: rebuild libcfhip with -DCF_LEGACY_HEADS (CF_EXTRA_FLAGS), " \
+                                               "or pack the heads for the 16x16x32 patch kernel (mfma16 = 1, layout3x3 = 1, n_out <= 16)", what)
+#endif
+
 extern "C" int cf_head_tail(const cf_head_tail_args* a, void* stream) {
   HeadTailK k{};
   const int rc = fill_tail(a, k, "cf_head_tail", true);
   if (rc != CF_OK) return rc;
+#ifdef CF_LEGACY_HEADS
   static CfLdsLimit lds_limit;
   lds_limit.ensure(head_tail_kernel, HT_LDS, HT_LDS);
   const int tiles = (k.M + HT_PX - 1) / HT_PX;
   hipLaunchKernelGGL(head_tail_kernel, dim3(tiles * a->n_heads), dim3(256), HT_LDS, (hipStream_t)stream, k);
   return cf_check_launch("cf_head_tail");
+#else
+  (void)stream;
+  CF_LEGACY_ONLY("cf_head_tail");
+  return CF_EINVAL;
+#endif
 }
 
 extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
@@ -1457,9 +1485,11 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
     const int n_groups = hp.group ? (a->tail.n_heads + hp.group - 1) / hp.group : 1;
     const long blocks = (long)hp.tiles_x * hp.tiles_y * a->tail.B * (hp.group ? (long)n_groups * hp.group : a->tail.n_heads);
     CF_REQUIRE(blocks < (1L << 31), "cf_head_fused: grid too large");
+#ifdef CF_LEGACY_HEADS
     static CfLdsLimit lim_plain, lim_pc;
     lim_plain.ensure(head_patch_kernel<4, false>, HP_LDS, HP_LDS);
     lim_pc.ensure(head_patch_kernel<4, true>, HP_LDS, HP_LDS);
+#endif
     if (m16) {
       // heads without hidden layers: a workgroup walks several heads on one patch (chosen below; CF_HEAD_LOOP overrides
       // for dev tools).  With hidden layers the chain rewrites the patch: one head per workgroup.
@@ -1526,18 +1556,28 @@ extern "C" int cf_head_fused(const cf_head_fused_args* a, void* stream) {
       else launch(head_patch16_kernel<4, false, false>, lim16[0]);
       return cf_check_launch("cf_head_fused");
     }
+#ifdef CF_LEGACY_HEADS
     if (a->n_src == 2)
       hipLaunchKernelGGL((head_patch_kernel<4, true>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
     else
       hipLaunchKernelGGL((head_patch_kernel<4, false>), dim3((unsigned)blocks), dim3(256), HP_LDS, (hipStream_t)stream, hp);
     return cf_check_launch("cf_head_fused");
+#else
+    (void)blocks;
+    CF_LEGACY_ONLY("cf_head_fused with 32x32x16 fragments (mfma16 = 0)");
+#endif
   }
   // the slot-table kernel reads every weight as 32x32x16 fragments: 16x16x32-packed ones would be misread silently
   CF_REQUIRE(a->mfma16 == 0, "cf_head_fused: mfma16 fragments need the 3x3 patch layout (layout3x3 = 1, 64-channel first "
                              "source [, 8-channel second]); this launch would run on the 32x32x16 slot-table kernel");
+#ifdef CF_LEGACY_HEADS
   static CfLdsLimit lds_limit;
   lds_limit.ensure(head_fused_kernel, HF_LDS, HF_LDS);
   const int tiles = (k.t.M + HT_PX - 1) / HT_PX;
   hipLaunchKernelGGL(head_fused_kernel, dim3(tiles * a->tail.n_heads), dim3(256), HF_LDS, (hipStream_t)stream, k);
   return cf_check_launch("cf_head_fused");
+#else
+  CF_LEGACY_ONLY("cf_head_fused on the slot-table kernel (layout3x3 = 0)");
+  return CF_EINVAL;
+#endif
 }

@@ -439,7 +439,7 @@ class _Plan:
                                layers[i - 1].data_ptr(), summed.data_ptr(), B, h, w, c, f))
                 layers[i] = dcn_node(f"{p}.node_{j}", summed, out=final_out if i == endp - 1 else None)
 
-        bf = bool(model.heads_bf16)                        # split-bf16 ("bf16x3") head GEMMs
+        bf = model._heads_bf()                             # fused split-bf16 head launches (False: the exact-fp32 layer-by-layer heads)
         h4, w4 = H // 4, W // 4
         self.h4, self.w4 = h4, w4
         self.in_step = None
@@ -535,18 +535,16 @@ class _Plan:
                 self.inputs["heads.secondary.0"] = [feat]
 
         def hconv(name, srcs, strides, out_c=None, out=None, out_offset=0, act=ACT_RELU):
-            """One hidden head layer: fp32 NHWC or split-bf16 NHWC, depending on model.heads_bf16."""
+            """One hidden head layer of the exact-fp32 heads (model.heads_bf16 = False): fp32 NHWC, cf_conv2d_fused."""
             pc = pk[name]
             if out is None:
-                out = buf(B, h4, w4, 2, out_c, dtype=torch.bfloat16) if bf else buf(B, h4, w4, out_c)
+                out = buf(B, h4, w4, out_c)
             stride = out.shape[-1]
-            a = ops.conv_args(pc, srcs, strides, B, h4, w4, out, stride, act, None, 0,
-                              LAYOUT_NHWC_SPLIT_BF16 if bf else LAYOUT_NHWC, None, out_offset, False,
-                              2 if bf else 4)
+            a = ops.conv_args(pc, srcs, strides, B, h4, w4, out, stride, act, None, 0, LAYOUT_NHWC, None, out_offset, False, 4)
             self.keep.append(a)
             self.step_index[name] = len(self.steps)
             self.step_flops[name] = 2.0 * M4 * pc.n * (pc.kh * pc.kh * sum(int(c) for c in pc.real_cin))
-            self.add_step((self.lib.cf_conv2d_bf16x3 if bf else self.lib.cf_conv2d_fused, C.byref(a)))
+            self.add_step((self.lib.cf_conv2d_fused, C.byref(a)))
             return out
 
         def head_out(h, src, src_stride):
@@ -558,27 +556,15 @@ class _Plan:
             self.keep.append(a)
             self.step_index[f"heads.{h}.out"] = len(self.steps)
             self.step_flops[f"heads.{h}.out"] = 2.0 * M4 * pc.n * 256
-            self.add_step((self.lib.cf_conv2d_bf16x3 if bf else self.lib.cf_conv2d_fused, C.byref(a)))
+            self.add_step((self.lib.cf_conv2d_fused, C.byref(a)))
             self.outs[h] = a
 
         hs = 256 * len(primary)
-        hid = None if (bf and model.heads_fused) else hconv("heads.primary.0", [feat_in], [64], out_c=hs)
+        hid = None if bf else hconv("heads.primary.0", [feat_in], [64], out_c=hs)
 
         def act_of(h):
             return ACT_SIGMOID_CLAMP if h == "heatmap" else (
                 ACT_RAW_AND_SIGDEPTH if h in ("depth", "depth2") else ACT_NONE)
-
-        def fused_tails(name, names, src, stride):
-            """One cf_head_tail launch for sibling heads; per-call outputs patched via self.tails."""
-            hd = [dict(pk[name][h], c_base=256 * n, act=act_of(h)) for n, h in enumerate(names)]
-            a = ops.head_tail_args(src, stride, B, h4, w4, hd)
-            self.keep.append(a)
-            for n, h in enumerate(names):
-                self.tails[h] = (a, n)
-            self.step_index[name] = len(self.steps)
-            self.step_flops[name] = sum(2.0 * M4 * 256 * (256 * len(pk[name][h]["w_hidden"]) + heads[h])
-                                        for h in names)
-            self.add_step((self.lib.cf_head_tail, C.byref(a)))
 
         def fused_heads(name, names, srcs, strides, pkname=None):
             """One cf_head_fused launch: 3x3 + ReLU + tail for sibling heads, hidden never in HBM."""
@@ -593,7 +579,7 @@ class _Plan:
                 for h, d in zip(names, hd))
             self.add_step((self.lib.cf_head_fused, C.byref(f)))
 
-        fuse_all = bf and bool(model.heads_fused)
+        fuse_all = bf
         # Two lanes for the decoder's index kernels (model.heads_lanes, fused heads): behind the primary launch the side stream
         # runs the decoder's NMS + top-k (handed to decode.py through the heat map tensor, see run()) beside the frustum
         # path and the secondary launch, instead of alone on the chip behind the last head launch.  (Splitting the primary
@@ -622,8 +608,6 @@ class _Plan:
                 peaks_lane()
         elif fuse_all:
             fused_heads("tails.primary", primary, [feat_in], [64])
-        elif bf:
-            fused_tails("tails.primary", primary, hid, hs)
         else:
             for h in primary:
                 head_out(h, hid, hs)
@@ -648,16 +632,12 @@ class _Plan:
                 if split:
                     self.ctl("wait", 0, self.ev_peaks)
                 return
-            s1 = hconv("heads.secondary.0", [feat_in, self.pc_hm8 if bf else self.pc_hm4],
-                       [64, 8 if bf else 4], out_c=ss)
-            if bf:
-                fused_tails("tails.secondary", SECONDARY_HEADS, s1, ss)
-            else:
-                s2 = buf(B, h4, w4, ss)
-                for n, h in enumerate(SECONDARY_HEADS):
-                    hconv(f"heads.{h}.2", [s1], [ss], out=s2, out_offset=256 * n)
-                    hconv(f"heads.{h}.4", [s2], [ss], out=s1, out_offset=256 * n)
-                    head_out(h, s1, ss)
+            s1 = hconv("heads.secondary.0", [feat_in, self.pc_hm4], [64, 4], out_c=ss)
+            s2 = buf(B, h4, w4, ss)
+            for n, h in enumerate(SECONDARY_HEADS):
+                hconv(f"heads.{h}.2", [s1], [ss], out=s2, out_offset=256 * n)
+                hconv(f"heads.{h}.4", [s2], [ss], out=s1, out_offset=256 * n)
+                head_out(h, s1, ss)
         elif split:
             self.ctl("wait", 0, self.ev_peaks)
 
@@ -879,6 +859,7 @@ class DLASeg(nn.Module):
         self.lanes_max_frames = 4  # ... up to this many 448x800-frame equivalents per plan
         self.streams = 2         # > 1 (and batch >= min_sub_batch * streams): backbone + neck as that many sub-batches on
                                  # concurrent HIP streams with their own plans; heads on the caller's stream
+        self.trunk_on_caller = True   # ... the last of those sub-batches on the caller's stream itself (one event wait less in front of the heads)
         self.min_sub_batch = 6   # ... and only when a sub-batch keeps at least this many 448x800-frame equivalents: measured (tools/
                                  # bench_small_batch.py, ms per forward + decode, one stream vs two): B=8 5.28 vs 5.91,
                                  # B=12 7.72 vs 6.86, B=16 9.16 vs 8.61 - four-frame trunks lose to one eight-frame forward
@@ -898,10 +879,9 @@ class DLASeg(nn.Module):
                                    # association kernel's prologue) instead of cf_topk_peaks + cf_frustum_assoc (3); same bits
         self.proj_fuse = True    # the sub-tree that opens a level: `project` of the pooled input as k-steps of tree1.conv2
                                  # (cf_conv3x3_proj_f16x3) instead of a launch + a residual tensor; set before the first forward
-        self.heads_bf16 = True   # head GEMMs on the bf16 MFMA pipe with split operands (cf_gemm_bf16.hip)
-        self.heads_fused = True  # with heads_bf16: one launch per head group, hidden maps stay in LDS
-        self.heads_mfma16 = True # fused heads: first layer + register-fed output layer on v_mfma_f32_16x16x32_bf16 (the
-                                 # shape that holds the higher clock under load: 1.72 vs 1.51 PFLOP/s measured)
+        self.heads_bf16 = True   # head GEMMs on the bf16 / f16 MFMA pipe with split operands: ONE cf_head_fused launch per head group
+                                 # on v_mfma_f32_16x16x32_* (hidden maps stay in LDS).  False - or a head with more than 16 outputs,
+                                 # which the 16-row output tile of that kernel does not hold - : exact-fp32 layer-by-layer heads
         self.heads_mx = True     # ... and the FIRST layer of every fused head as fp16 main term + block-scaled FP6 cross terms
                                  # (v_mfma_scale_f32_16x16x128_f8f6f4): 1.5 MFMA passes per product instead of 3; hidden and
                                  # output layers stay bf16x3 (the float64-anchored gate rejects FP6 cross terms there)
@@ -1056,7 +1036,7 @@ class DLASeg(nn.Module):
         for h in heads:
             if any(c != 256 for c in head_conv[h]):
                 raise NotImplementedError("head_conv widths other than 256 are not on the path")
-        bf = bool(self.heads_bf16)
+        bf = self._heads_bf()
         pack = packing.pack_conv_bf16 if bf else packing.pack_conv
         feat_src = Source(64, 64)
         pc_src = Source(3, 8 if bf else 4)
@@ -1078,9 +1058,7 @@ class DLASeg(nn.Module):
                     pk[f"heads.{h}.{idx}"] = pack(hw(h, idx), hb(h, idx), [Source(256, ns, 256 * n)]).to(device)
                 pk[f"heads.{h}.out"] = pack(hw(h, 6), hb(h, 6), [Source(256, ns, 256 * n)]).to(device)
         if bf:
-            # 16x16x32 fragments only where the kernel that reads them runs: the fused patch kernels (cf_head_tail and
-            # the slot-table head kernel read 32x32x16 fragments)
-            m16 = bool(self.heads_mfma16) and bool(self.heads_fused) and all(n <= 16 for n in heads.values())
+            m16 = True               # 16x16x32 fragments: what head_patch16_kernel reads (_heads_bf: every head has <= 16 outputs)
             def tail(h, hidden_idx, out_idx):
                 n_out = heads[h]
                 b32 = torch.zeros(32)
@@ -1110,6 +1088,11 @@ class DLASeg(nn.Module):
                 pk["tails.secondary"] = {h: dict(tail(h, [2, 4], 6), **first(h, [feat_src, pc_src]))
                                          for h in SECONDARY_HEADS}
         self._packed = pk
+
+    def _heads_bf(self):
+        """The heads run as fused split-operand launches (cf_head_fused on 16x16x32 fragments): model.heads_bf16 and every head's
+        output count fits that kernel's one 16-row output tile; otherwise the exact-fp32 layer-by-layer heads."""
+        return bool(self.heads_bf16) and all(int(n) <= 16 for n in self.config.heads.values())
 
     # ----------------------------------------------------------------------------- dynamic range
     def _range_groups(self):
@@ -1385,7 +1368,7 @@ class DLASeg(nn.Module):
         h4, w4 = H // 4, W // 4
         cur = torch.cuda.current_stream(dev)
         pool = _side_streams(dev, sid, n)
-        bf = bool(self.heads_bf16)
+        bf = self._heads_bf()
 
         def heads_plan():
             feat = torch.empty((B, h4, w4, 64), device=dev, dtype=torch.float32)
@@ -1397,13 +1380,17 @@ class DLASeg(nn.Module):
 
         hplan = self._plan((B, H, W, dev, sid, "heads", n), heads_plan, store)
         spans = []
+        # model.trunk_on_caller: the LAST trunk is issued on the caller's stream itself (behind the forks of the others), so the
+        # heads follow its last launch in stream order and wait for n - 1 events instead of n
+        on_cur = bool(self.trunk_on_caller)
         for i in range(n):
             sl = slice(i * k, (i + 1) * k)
             tplan = self._plan((B, H, W, dev, sid, "trunk", i, n),
                                lambda: _Plan(self, k, H, W, dev, part="trunk", feat=hplan.feat[sl],
                                              feat_in=hplan.feat_in[sl] if bf else None), store)
-            s = pool[i]
-            s.wait_stream(cur)
+            s = cur if (on_cur and i == n - 1) else pool[i]
+            if s is not cur:
+                s.wait_stream(cur)
             with torch.cuda.stream(s):
                 if self.record_spans:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1412,7 +1399,7 @@ class DLASeg(nn.Module):
                 if self.record_spans:
                     e1.record(s)
                     spans.append((e0, e1))
-        for s in pool:
+        for s in (pool[:n - 1] if on_cur else pool):
             cur.wait_stream(s)
         if self.record_spans:
             self.trunk_spans = spans

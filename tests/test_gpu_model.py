@@ -206,12 +206,14 @@ def test_forward_matches_reference_golden(dev, golden_dir, tag, radar, B, H, W):
 
 
 @pytest.mark.parametrize("flags", [dict(heads_mx=False), dict(pack_mx_fused=False), dict(proj_fuse=False, stem_pool=False),
-                                   dict(conv_patch=False)],
-                         ids=["heads_bf16x3", "separate_pack_pass", "project_and_pool_launches", "slot_kernels_only"])
+                                   dict(conv_patch=False), dict(heads_bf16=False), dict(conv_f16=False, heads_bf16=False)],
+                         ids=["heads_bf16x3", "separate_pack_pass", "project_and_pool_launches", "slot_kernels_only",
+                              "exact_fp32_heads", "exact_fp32_build"])
 def test_forward_matches_reference_golden_on_the_switchable_head_paths(dev, golden_dir, flags):
     """(also: `proj_fuse = False`, `stem_pool = False` - the four `project` convolutions and the level-2 max-pool as their own
     launches, bench.py --no-proj-fuse --no-stem-pool - and `conv_patch = False` - every f16x3 convolution on the slot kernel, conv2 + project from its two-source
-    slot table - against the same goldens.)
+    slot table - against the same goldens; `heads_bf16 = False`: the exact-fp32 layer-by-layer heads, also what a head with more than
+    16 outputs gets; with `conv_f16 = False` the exact-fp32 build of bench.py --exact-fp32.)
     the A/B switches of the heads' first layer keep working at module level: `heads_mx = False` (bf16x3, the round-4
     arithmetic - bench.py --heads-bf16x3) against the reference's golden outputs with the same tolerance, and
     `pack_mx_fused = False` (cf_pack_feat_mx as its own launch instead of the DCN epilogue): same tolerance, and bit-identical to the
@@ -228,10 +230,13 @@ def test_forward_matches_reference_golden_on_the_switchable_head_paths(dev, gold
     with torch.no_grad():
         y = m(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))[0]
         ref = _model(True, dev, (H, W))(x.to(dev), pc_dep=pc_dep.to(dev), calib=calib.to(dev))[0]
-    assert m._mx_active == bool(flags.get("heads_mx", True))
+    assert m._mx_active == (bool(flags.get("heads_mx", True)) and bool(flags.get("heads_bf16", True)))
+    launched = {st[0].__name__ for plan in m._all_plans() for st in plan.steps if st and not isinstance(st[0], str)}
+    assert ("cf_head_fused" in launched) == bool(flags.get("heads_bf16", True))
     names = {n for plan in m._all_plans() for n in plan.step_index}
-    assert any(n.endswith(".project") for n in names) == (not flags.get("proj_fuse", True))
-    assert any(n.endswith(".conv2+project") for n in names) == flags.get("proj_fuse", True)
+    proj_fused = flags.get("proj_fuse", True) and flags.get("conv_f16", True)      # (the exact-fp32 build fuses nothing)
+    assert any(n.endswith(".project") for n in names) == (not proj_fused)
+    assert any(n.endswith(".conv2+project") for n in names) == proj_fused
     for k, v in y.items():
         if k == "calib":
             continue
@@ -691,33 +696,6 @@ def test_two_lane_neck_equals_single_stream(dev, radar, B, H, W):
         for k in one:
             if k != "calib":
                 assert torch.equal(y[k], one[k]), k
-
-
-@pytest.mark.parametrize("radar", [True, False])
-def test_unfused_head_path_matches_fused(dev, radar):
-    """model.heads_fused = False (first layers as cf_conv2d_bf16x3, tails as cf_head_tail - 32x32x16 fragments) with
-    the default heads_mfma16 = True: round 2 packed 16x16x32 fragments for kernels that read 32x32x16 ones and the
-    outputs were silently wrong.  Both paths against the oracle, and against each other within bf16x3
-    rounding."""
-    H, W, B = 128, 160, 2
-    sd = cases.tuned_state_dict(radar=radar, seed=0)
-    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=3, radar=radar)
-    kw = dict(pc_dep=pc_dep.to(dev), calib=calib.to(dev)) if radar else {}
-    with torch.no_grad():
-        ref = model_ref.forward(sd, x, pc_dep=pc_dep if radar else None, calib=calib, radar=radar)[0]
-        outs = {}
-        for fused in (True, False):
-            m = _model(radar, dev, (H, W))
-            assert m.heads_mfma16
-            m.heads_fused = fused
-            outs[fused] = m(x.to(dev), **kw)[0]
-            names = {s[0].__name__ for p in m._plans.values() for s in p.steps if s and not isinstance(s[0], str)}
-            assert ("cf_head_tail" in names) == (not fused) and ("cf_head_fused" in names) == fused
-    for k, v in ref.items():
-        if k == "calib":
-            continue
-        for fused in (True, False):
-            _assert_maps_close(outs[fused][k].cpu(), v, f"{k}[fused={fused}]")
 
 
 def test_plan_cache_is_an_lru_and_frees_evicted_buffers(dev):

@@ -386,101 +386,46 @@ def test_split_bf16_roundtrip(dev):
     assert torch.equal(hi, x.to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("B,srcs,Co,H,W,k,act", [
-    (2, [(64, 64)], 256, 28, 50, 3, 1),                   # head first layer
-    (1, [(64, 64), (3, 8)], 128, 23, 31, 3, 1),           # feat || pc_hm, ragged M
-    (2, [(256, 256)], 256, 16, 24, 1, 1),                 # hidden 1x1
-])
-def test_conv2d_bf16x3_split_output(dev, B, srcs, Co, H, W, k, act):
-    from centerfusiondetect3d_amd import ops, packing
-    xs = [rnd(B, c, H, W, seed=10 + i) for i, (c, _) in enumerate(srcs)]
-    ci = sum(c for c, _ in srcs)
-    w, b = rnd(Co, ci, k, k, seed=2, scale=(ci * k * k) ** -0.5), rnd(Co, seed=3)
-    ref = F.conv2d(torch.cat(xs, 1), w, b, 1, k // 2)
-    if act:
-        ref = F.relu(ref)
-    pc = packing.pack_conv_bf16(w, b, [packing.Source(c, s) for c, s in srcs]).to(dev)
-    out = ops.conv2d_bf16x3(pc, [_split(x, dev, cs=s) for x, (_, s) in zip(xs, srcs)], B, H, W, act=act)
-    assert out.shape == (B, H, W, 2, Co)
-    got = _unsplit(out).cpu()
-    scale = float(ref.abs().max())
-    assert float((got - ref).abs().max()) < 3e-5 * scale, float((got - ref).abs().max()) / scale
-
-
-def test_conv2d_bf16x3_nchw_outputs_and_slices(dev):
-    from centerfusiondetect3d_amd import ops, packing
-    B, H, W = 2, 9, 14                                     # HoWo not a multiple of 4
-    hid = rnd(B, 1024, H, W, seed=1)
-    hs = _split(hid, dev)
-    for n, co in ((0, 10), (2, 1), (3, 8)):
-        w, b = rnd(co, 256, 1, 1, seed=4 + n, scale=1 / 16), rnd(co, seed=5)
-        raw = F.conv2d(hid[:, 256 * n:256 * (n + 1)], w, b)
-        pc = packing.pack_conv_bf16(w, b, [packing.Source(256, 1024, 256 * n)]).to(dev)
-        scale = float(raw.abs().max())
-        got = ops.conv2d_bf16x3(pc, [hs], B, H, W, layout=1)
-        assert float((got.cpu() - raw).abs().max()) < 3e-5 * scale
-        got = ops.conv2d_bf16x3(pc, [hs], B, H, W, layout=1, act=2)
-        close(got, torch.clamp(torch.sigmoid(raw), 1e-4, 1 - 1e-4), 1e-4, 1e-5)
-        o1, o2 = ops.conv2d_bf16x3(pc, [hs], B, H, W, layout=1, act=3)
-        assert float((o1.cpu() - raw).abs().max()) < 3e-5 * scale
-        close(o2, 1.0 / (torch.sigmoid(raw) + 1e-6) - 1.0, 1e-3, 1e-3)
-
-
-@pytest.mark.parametrize("n_hidden,B,H,W", [(0, 2, 9, 14), (2, 1, 16, 20), (1, 2, 7, 9)])
-def test_head_tail_fused_chain(dev, n_hidden, B, H, W):
-    """x -> [relu(W x + b)] x n_hidden -> W_out x + b_out, several sibling heads in one launch,
-    hidden tile resident in LDS; checked against plain fp32 torch."""
-    from centerfusiondetect3d_amd import ops, packing
-    n_outs, acts = [10, 1, 8, 3], [2, 3, 0, 0]
-    hid = F.relu(rnd(B, 256 * len(n_outs), H, W, seed=1))
-    hs = _split(hid, dev)
-    heads, refs, keep = [], [], []
-    for i, (no, act) in enumerate(zip(n_outs, acts)):
-        x = hid[:, 256 * i:256 * (i + 1)]
-        wh, bh = [], []
-        for l in range(n_hidden):
-            w, b = rnd(256, 256, 1, 1, seed=10 * i + l, scale=1 / 16), rnd(256, seed=50 + 10 * i + l, scale=0.1)
-            x = F.relu(F.conv2d(x, w, b))
-            wh.append(packing.pack_fragments(w.view(256, 256)).to(dev)); bh.append(b.to(dev))
-        w, b = rnd(no, 256, 1, 1, seed=100 + i, scale=1 / 16), rnd(no, seed=200 + i)
-        raw = F.conv2d(x, w, b)
-        b32 = torch.zeros(32); b32[:no] = b
-        out = torch.full((B, no, H, W), float("nan"), device=dev)
-        out2 = torch.full((B, no, H, W), float("nan"), device=dev) if act == 3 else None
-        heads.append(dict(c_base=256 * i, w_hidden=wh, b_hidden=bh, w_out=packing.pack_fragments(w.view(no, 256)).to(dev),
-                          b_out=b32.to(dev), n_out=no, act=act, out=out, out2=out2))
-        refs.append(raw)
-    a = ops.head_tail_args(hs, 256 * len(n_outs), B, H, W, heads)
-    ops.run_head_tail(a)
-    for hd, raw in zip(heads, refs):
-        scale = float(raw.abs().max())
-        tol = 6e-5 * scale * (1 + n_hidden)
-        got = hd["out"].cpu()
-        if hd["act"] == 2:
-            close(got, torch.clamp(torch.sigmoid(raw), 1e-4, 1 - 1e-4), 1e-4, 1e-5)
-        else:
-            assert float((got - raw).abs().max()) < tol, float((got - raw).abs().max()) / scale
-        if hd["act"] == 3:
-            close(hd["out2"], 1.0 / (torch.sigmoid(raw) + 1e-6) - 1.0, 1e-3, 1e-3)
+def test_legacy_head_kernels_are_not_in_the_default_build(dev):
+    """The kernels of rounds 1-3 that nothing dispatches any more - cf_conv2d_bf16x3 (unfused heads), cf_head_tail, cf_head_fused
+    on 32x32x16 fragments or on the slot table - are compiled only with -DCF_LEGACY_HEADS: the default library still exports the
+    entry points (include/cf_hip.h) and answers them with an error that says so, never with a wrong result."""
+    from centerfusiondetect3d_amd import ops, packing, _lib
+    B, H, W = 1, 8, 16
+    x = rnd(B, 64, H, W, seed=1)
+    w, b = rnd(256, 64, 3, 3, seed=2, scale=1 / 24), rnd(256, seed=3)
+    pc = packing.pack_conv_bf16(w, b, [packing.Source(64, 64)]).to(dev)
+    with pytest.raises(_lib.CfHipError, match="legacy kernel path"):
+        ops.conv2d_bf16x3(pc, [_split(x, dev)], B, H, W, act=1)
+    hid = _split(F.relu(rnd(B, 256, H, W, seed=4)), dev)
+    wo = rnd(8, 256, seed=5, scale=1 / 16)
+    head = dict(c_base=0, w_hidden=[], b_hidden=[], w_out=packing.pack_fragments(wo).to(dev), b_out=torch.zeros(32, device=dev),
+                n_out=8, act=0, out=torch.empty(B, 8, H, W, device=dev), out2=None)
+    with pytest.raises(_lib.CfHipError, match="legacy kernel path"):
+        ops.run_head_tail(ops.head_tail_args(hid, 256, B, H, W, [head]))
+    pc32 = packing.pack_conv_bf16(w, b, [packing.Source(64, 64)], fragments=True).to(dev)           # 32x32x16 fragments
+    h32 = dict(head, w_first=pc32.weight, b_first=pc32.bias[:256].contiguous(), w_out_perm=packing.pack_fragments(wo, acc_order=True).to(dev),
+               mfma16=False)
+    f = ops.head_fused_args([_split(x, dev)], [64], pc32.slots, pc32.k_pad, B, H, W, [h32])
+    assert f.layout3x3 == 1 and f.mfma16 == 0
+    with pytest.raises(_lib.CfHipError, match="legacy kernel path"):
+        ops.run_head_fused(f)
+    f0 = ops.head_fused_args([_split(x, dev)], [64], pc32.slots, pc32.k_pad, B, H, W, [dict(h32, w_out_perm=None)])
+    assert f0.layout3x3 == 0
+    with pytest.raises(_lib.CfHipError, match="legacy kernel path"):
+        ops.run_head_fused(f0)
 
 
 @pytest.mark.parametrize("n_hidden,radar,B,H,W,patch", [
-    (0, False, 2, 9, 14, False), (2, True, 1, 16, 20, False), (1, True, 2, 7, 9, False),
-    (0, False, 2, 9, 14, True),       # 2-D patch kernel: one partial 8x16 tile per image
-    (0, True, 1, 21, 37, True),       # ... with the pc_hm taps, ragged tiles in both directions
-    (0, False, 3, 16, 32, True),      # ... exact tiling
-    (2, True, 2, 13, 19, True),       # hidden layers behind the patch first layer (two 64-pixel halves)
-    (1, False, 1, 8, 40, True),
-    (0, False, 2, 9, 14, 16),         # the same on the 16x16x32 MFMA shape (fragments packed by pack_fragments16)
-    (0, True, 1, 21, 37, 16),
-    (0, False, 3, 16, 32, 16),
-    (2, True, 2, 13, 19, 16),
+    (0, False, 2, 9, 14, 16),         # 2-D patch kernel on the 16x16x32 MFMA shape: one partial 8x16 tile per image
+    (0, True, 1, 21, 37, 16),         # ... with the pc_hm taps, ragged tiles in both directions
+    (0, False, 3, 16, 32, 16),        # ... exact tiling
+    (2, True, 2, 13, 19, 16),         # hidden layers behind the patch first layer
     (1, False, 1, 8, 40, 16),
 ])
 def test_head_fused_whole_head(dev, n_hidden, radar, B, H, W, patch):
-    """3x3 conv (feat [|| pc_hm]) + ReLU -> hidden chain -> output, one launch, vs fp32 torch.
-    patch: heads without hidden layers on the 2-D LDS-patch kernel (w_out_perm given); patch == 16: that kernel's
-    v_mfma_f32_16x16x32_bf16 form."""
+    """3x3 conv (feat [|| pc_hm]) + ReLU -> hidden chain -> output, one launch, vs fp32 torch: the 2-D LDS-patch kernel on
+    v_mfma_f32_16x16x32_bf16 fragments (patch == 16; the 32x32x16 and slot-table forms of rounds 1-3 are legacy builds only)."""
     m16 = patch == 16
     patch = bool(patch)
     from centerfusiondetect3d_amd import ops, packing

@@ -176,7 +176,7 @@ LAYER_OF = {"level5": "base.level5.tree1.conv2", "stem": "base.level0", "x2": "b
 @pytest.mark.parametrize("kind", ["level5", "stem", "x2", "feat"])
 def test_range_guard_raises_and_calibration_matches_the_oracle(dev, kind):
     from centerfusiondetect3d_amd import getModel, centerfusion_middle_config, _lib
-    B, H, W = 2, 128, 160
+    B, H, W = 1, 128, 160
     K = 4096.0
     sd = _boost(cases.tuned_state_dict(radar=True, seed=0), kind, K)
     x, pc_dep, calib = cases.model_inputs(B, H, W, seed=1, radar=True)

@@ -12,7 +12,6 @@ ap.add_argument("--fp32-heads", action="store_true")
 ap.add_argument("--no-precise", action="store_true")
 ap.add_argument("--fp32-convs", action="store_true")
 ap.add_argument("--iters", type=int, default=5)
-ap.add_argument("--heads-mfma32", action="store_true", help="head kernels on the 32x32x16 MFMA shape (A/B)")
 ap.add_argument("--heads-bf16x3", action="store_true", help="heads' first layers on bf16x3 instead of fp16 + FP6 (A/B)")
 ap.add_argument("--no-proj-fuse", action="store_true", help="the `project` convolutions as their own launches (A/B)")
 a = ap.parse_args()
@@ -22,7 +21,6 @@ m = getModel(centerfusion_middle_config((H, W)))
 m.heads_bf16 = not a.fp32_heads
 m.precise = not a.no_precise
 m.conv_f16 = not a.fp32_convs
-m.heads_mfma16 = not a.heads_mfma32
 m.heads_mx = not a.heads_bf16x3
 m.proj_fuse = not a.no_proj_fuse
 m.streams = 1          # per-launch event timing needs one stream
