@@ -117,6 +117,8 @@ int cf_stem_fused(const cf_stem_args* a, void* stream);
  * [N_pad][2][K_pad] bf16 (hi plane, lo plane); out is either CF_LAYOUT_NHWC_SPLIT_BF16
  * (out_stride = channels per plane) or CF_LAYOUT_NCHW fp32; residual / precise are ignored. */
 int cf_conv2d_bf16x3(const cf_conv_args* a, void* stream);
+/* (ABI 6) LEGACY: the unfused heads of rounds 1-2.  Compiled only with -DCF_LEGACY_HEADS; the default library keeps the export and
+ * answers it with CF_EINVAL ("legacy kernel path") - every bf16x3 layer of the path runs inside cf_head_fused. */
 
 /* cf_conv2d_f16x3: cf_conv2d_fused semantics (fp32 NHWC sources / residual / output, bias, ReLU) with
  * the products evaluated on the f16 MFMA pipe from split operands (x = hi + lo fp16 after a
@@ -236,6 +238,8 @@ typedef struct cf_head_tail_args {
   int32_t act[CF_MAX_HEADS];
 } cf_head_tail_args;
 int cf_head_tail(const cf_head_tail_args* a, void* stream);
+/* (ABI 6) LEGACY as a stand-alone launch (CF_LEGACY_HEADS builds only; CF_EINVAL otherwise): the argument block lives on as
+ * cf_head_fused_args.tail, whose layers run inside the fused launch. */
 
 /* cf_head_fused: a whole head group in one launch: 3x3 conv (sources -> 256) + ReLU, then the tail
  * of cf_head_tail (tail.x / tail.x_stride / tail.c_base are ignored: the hidden tile is produced in
@@ -273,6 +277,9 @@ typedef struct cf_head_fused_args {
   float first_scale[CF_MAX_HEADS];         /* mx: 2^-(s+4) of head i's first layer (applied where b_first is added) */
 } cf_head_fused_args;
 int cf_head_fused(const cf_head_fused_args* a, void* stream);
+/* (ABI 6) the default library runs the forms the host dispatches - layout3x3 = 1 with mfma16 = 1 (16x16x32 fragments, n_out <= 16),
+ * mx = 0 or 1; the 32x32x16 patch kernel (mfma16 = 0) and the slot-table kernel (layout3x3 = 0) are CF_LEGACY_HEADS builds only
+ * (CF_EINVAL otherwise). */
 
 /* cf_pack_feat_mx: fp32 NHWC feature map [M][in_stride] (64 channels used) -> [M][272] bytes for cf_head_fused with mx = 1:
  * per pixel four 64-byte segments g = 0..3 - [8 fp16: hi channels 8g..8g+7][8 fp16: hi channels 32+8g..32+8g+7][FP6 block g:

@@ -321,3 +321,40 @@ def test_integration_md_snippets_parse_and_import_real_names():
                     for kw in node.keywords:
                         assert kw.arg in params, f"INTEGRATION.md passes {kw.arg}= to {name}"
                     assert len(node.args) <= len([p for p in params if p != "self"]), name
+
+
+def test_range_guard_host_logic():
+    """The host side of the dynamic-range guard without a GPU: the pre-scale rule, the calibration
+    state and what voids it, and the argument blocks carrying in_scale / out_scale as the C ABI documents them."""
+    import math
+    from centerfusiondetect3d_amd import ops, _lib
+    # the rule: 16 while max |x| * 16 leaves a factor 4 to 65504, else the largest power of two with max |x| * s <= 65504 / 8
+    assert ops.in_scale_for(0.0) == ops.in_scale_for(1.0) == ops.in_scale_for(1023.0) == 16.0
+    for a in (1024.0, 2047.0, 4094.0, 5000.0, 65504.0, 1e6, 2.3e7, 3e30):
+        s = ops.in_scale_for(a)
+        assert s < 16.0 and math.frexp(s)[0] == 0.5                      # a power of two
+        assert a * s <= 65504.0 / 8.0 < a * s * 2.0                      # the largest one inside the headroom
+    assert ops.in_scale_for(5000.0, headroom=2.0) == 4.0
+    for bad in (float("nan"), float("inf")):
+        with pytest.raises(_lib.CfHipError, match="not finite"):
+            ops.in_scale_for(bad)
+    # argument blocks: in_scale = 0 (= 16) by default, out_scale follows a calibrated in_scale
+    w, b = torch.randn(64, 64, 3, 3) * 0.05, torch.zeros(64)
+    pc = packing.pack_conv_f16(w, b, [packing.Source(64, 64)])
+    x = torch.zeros(1, 8, 8, 64)
+    a0 = ops.conv_args(pc, [x], [64], 1, 8, 8, x, 64)
+    a1 = ops.conv_args(pc, [x], [64], 1, 8, 8, x, 64, in_scale=0.5)
+    assert a0.in_scale == 0.0 and a0.out_scale == pytest.approx(pc.out_scale)
+    assert a1.in_scale == 0.5 and a1.out_scale == pytest.approx(pc.out_scale * 32.0)
+    # calibration state of the module: set / get, scales, and load_state_dict voids it
+    m = getModel(centerfusion_middle_config((64, 64)))
+    assert m.calibration() is None and m._range_checked is False and m._scale("base.level2.tree1.conv1") is None
+    m.set_calibration({"base.level2.tree1.conv1": 10.0, "base.level5.tree1.conv2": 40000.0, "base.level5.project": 9.0,
+                       "heads.primary.0": 3000.0})
+    assert m._range_checked and m.calibration()["base.level5.tree1.conv2"] == 40000.0
+    assert m._scale("base.level2.tree1.conv1") == 16.0 and m._scale("base.level5.tree1.conv2") == 0.125
+    assert m._scale("base.level3.tree1.conv1") is None                  # not measured: the default
+    m.load_state_dict(m.state_dict())
+    assert m.calibration() is None and m._range_checked is False
+    with pytest.raises(_lib.CfHipError):
+        m.measure_ranges(torch.zeros(1, 3, 64, 64))                     # device tensors only: no CPU path
