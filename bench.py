@@ -837,6 +837,7 @@ def main():
                         "36 x the unique input) / average launch duration, against the guide's chip-wide L2-resident row-gather rate "
                         "(16.8-18.8 TB/s, MI355X_MICROARCH.md 'Indexed rows: gather into LDS'); launches of the two trunk streams "
                         "overlap, so a launch's duration includes what runs beside it; its MFMA-roofline frac is ~0.05",
+                "traffic": measured_traffic(prefixes=("dcn_f16x3_kernel<2, 2, 1, true, 1>",)),   # HBM-side bytes per launch (all 20 launches of the form)
                 "bytes_per_launch": g_b, "avg_launch_ms": round(g_avg_ms, 4), "launches_timed": g_n}
         default_run = (B, H, W) == (16, 448, 800) and not args.exact_fp32 and args.offset_std == 0.01
         if not args.no_cpu_baseline and world == 1:

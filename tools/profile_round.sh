@@ -22,8 +22,8 @@ for cfg in c2 c5; do
   rocprofv3 --pmc $SQ --kernel-trace -d $OUT/${cfg}_sq -- python3 $ARGS > $OUT/${cfg}_sq.log 2>&1
   echo "$cfg sq done"
 done
-python3 tools/pmc_traffic.py $OUT/c2_fetch $OUT/c2_write $OUT/c2_pmc_hbm_traffic.json 7 > $OUT/c2_traffic.txt
-python3 tools/pmc_traffic.py $OUT/c5_fetch $OUT/c5_write $OUT/c5_pmc_hbm_traffic.json 7 > $OUT/c5_traffic.txt
+python3 tools/pmc_traffic.py $OUT/c2_fetch $OUT/c2_write $OUT/c2_pmc_hbm_traffic.json 11 > $OUT/c2_traffic.txt
+python3 tools/pmc_traffic.py $OUT/c5_fetch $OUT/c5_write $OUT/c5_pmc_hbm_traffic.json 11 > $OUT/c5_traffic.txt
 python3 tools/pmc_kernels.py $OUT/c2_sq --top 30 > $OUT/c2_pmc_mfma_util.txt
 python3 tools/pmc_kernels.py $OUT/c5_sq --top 30 > $OUT/c5_pmc_mfma_util.txt
 for cfg in c2 c5; do
