@@ -292,6 +292,43 @@ def test_topk_frustum_two_launches_equal_the_three(dev, seed, B, H, W):
                                                 calib.to(dev), pcd.to(dev), 60.0))
 
 
+def test_topk_and_guard_at_large_k(dev):
+    """K above 128 takes the other branches of the round-6 kernels: 256 group maxima in the register-cached slice kernel, 38-49 KB
+    of merge scratch (tree merge in `topk_merge_kernel`, in the frustum prologue and in the guard's one-workgroup fallback,
+    which needs its dynamic-LDS limit raised beside 33 KB of static LDS)."""
+    from centerfusiondetect3d_amd import ops
+    g = torch.Generator().manual_seed(21)
+    heat = torch.rand(2, 10, 112, 200, generator=g)
+    for K in (129, 200, 256):
+        _check_topk(dev, heat, K, False)
+        _check_topk(dev, heat, K, True)
+    # the guard: unchanged map -> the carried peaks stand (even if they are garbage); changed map -> recomputed, = cf_topk_peaks
+    K = 256
+    hd = heat.to(dev)
+    ref = ops.topk_peaks(hd, K, nms=True)
+    sums = torch.empty(2 * ops.CHECKSUM_PARTS, device=dev, dtype=torch.int64)
+    ops.checksum64(hd, out=sums[:ops.CHECKSUM_PARTS])
+    ops.checksum64(hd, out=sums[ops.CHECKSUM_PARTS:])
+    assert torch.equal(sums[:ops.CHECKSUM_PARTS], sums[ops.CHECKSUM_PARTS:])
+    carried = tuple(torch.full_like(t, 7) for t in ref)
+    out = ops.topk_peaks(hd, K, nms=True, out=carried, only_if_changed=sums)
+    assert all(bool((t == 7).all()) for t in out)                      # equal sums: nothing ran
+    hd[1, 4, 50, 60] = 2.0                                             # one element changes
+    ops.checksum64(hd, out=sums[ops.CHECKSUM_PARTS:])
+    assert int((sums[:ops.CHECKSUM_PARTS] != sums[ops.CHECKSUM_PARTS:]).sum()) == 1     # exactly one part sees it
+    out = ops.topk_peaks(hd, K, nms=True, out=carried, only_if_changed=sums)
+    ref2 = ops.topk_peaks(hd, K, nms=True)
+    assert all(torch.equal(a, b) for a, b in zip(out, ref2)) and not torch.equal(ref2[0], ref[0])
+    # frustum chain at K = 160: two launches = three launches
+    y, pc_dep, calib = cases.frustum_case(3, B=2, K=160)
+    d = {k: v.to(dev) for k, v in y.items()}
+    _, inds, _ = ops.topk_peaks(d["heatmap"], 160, nms=False)
+    a = ops.frustum_assoc(inds, d["depth"], d["widthHeight"], d["dimension"], d["rotation"], calib.to(dev), pc_dep.to(dev), 60.0)
+    b = ops.topk_frustum(d["heatmap"], d["depth"], d["widthHeight"], d["dimension"], d["rotation"], calib.to(dev), pc_dep.to(dev), 160, 60.0)
+    assert torch.equal(a, b) and int((a != 0).sum()) > 0
+    assert np.array_equal(a.cpu().numpy(), frustum_ref.pc_frustum_heatmap(y, pc_dep, calib, 160, 60.0).numpy())
+
+
 def test_frustum_no_radar_and_single_box(dev):
     from centerfusiondetect3d_amd import ops
     y, pc_dep, calib = cases.frustum_case(5, B=1)
