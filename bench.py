@@ -585,7 +585,7 @@ def main():
     ap.add_argument("--root-fuse-children", action="store_true",
                     help="A/B: conv2 + Root in one launch also for the Roots that read the Tree's children (model.root_fuse_children)")
     ap.add_argument("--lanes-max-frames", type=int, default=None,
-                    help="A/B: model.lanes_max_frames (default 4: a trunk of up to that many 448x800-frame equivalents issues its IDA "
+                    help="A/B: model.lanes_max_frames (default 10; trunk sub-batches of the two-stream forward: at most 4: a forward of up to that many 448x800-frame equivalents issues its IDA "
                          "projections on a side stream beside the node chain)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="experiment (never the default line): consecutive steps alternate over this many caller streams, so the "

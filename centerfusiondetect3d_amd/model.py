@@ -258,7 +258,10 @@ class _Plan:
         self.n_events = 0
         # two-lane issue of the neck for small batches (a launch cannot fill the chip there); never with the timed /
         # graph paths, which want one stream
-        self.use_lanes = bool(model.lanes) and part != "heads" and B * (H // 4) * (W // 4) <= model.lanes_max_frames * 112 * 200
+        # (a trunk sub-batch of the two-stream forward keeps round 5's limit of 4 frames: its side lane would be a third / fourth
+        #  stream beside the other trunk, and the event traffic of that costs more than the overlap gives)
+        self.use_lanes = bool(model.lanes) and part != "heads" and \
+            B * (H // 4) * (W // 4) <= (model.lanes_max_frames if part == "all" else min(4, model.lanes_max_frames)) * 112 * 200
         self.keep = []           # keeps arg blocks / buffers alive
         self.bytes = 0
         self.step_index = {}     # conv name -> index in self.steps
@@ -856,7 +859,8 @@ class DLASeg(nn.Module):
         self.precise = True      # two-level fp32 summation in backbone + neck (see cf_gemm.hip)
         self.conv_f16 = True     # backbone / offset convs: fp32 storage, split-fp16 products (cf_gemm_f16.hip)
         self.lanes = True        # small batches: the IDA projections on a side stream beside the node chain (_Plan.ida)
-        self.lanes_max_frames = 4  # ... up to this many 448x800-frame equivalents per plan
+        self.lanes_max_frames = 10 # ... up to this many 448x800-frame equivalents per single-stream forward (round 6, ms per step with /
+                                   # without: bs 5 3.35 / 3.39, 6 4.00 / 4.08, 7 4.23 / 4.31, 8 4.60 / 4.67, 10 5.26 / 5.35, 11 5.69 / 5.67)
         self.streams = 2         # > 1 (and batch >= min_sub_batch * streams): backbone + neck as that many sub-batches on
                                  # concurrent HIP streams with their own plans; heads on the caller's stream
         self.trunk_on_caller = True   # ... the last of those sub-batches on the caller's stream itself (one event wait less in front of the heads)

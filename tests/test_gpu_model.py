@@ -677,7 +677,7 @@ def test_one_model_two_streams_two_threads(dev):
     assert len(sids) >= 3                                             # default stream + the two side streams
 
 
-@pytest.mark.parametrize("radar,B,H,W", [(True, 1, 448, 800), (True, 3, 128, 160), (False, 2, 96, 128)])
+@pytest.mark.parametrize("radar,B,H,W", [(True, 1, 448, 800), (True, 3, 128, 160), (False, 2, 96, 128), (True, 6, 448, 800)])
 def test_two_lane_neck_equals_single_stream(dev, radar, B, H, W):
     """model.lanes (small batches): the IDA projections issued on a side stream beside the node chain - bit for bit
     the single-stream forward, also when repeated back to back (cross-lane events, no shared scratch)."""
