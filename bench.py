@@ -356,7 +356,7 @@ def other_configs(dev, steps=12):
                               "per conv-like layer) / time; the counters (`traffic`, `measured_gbs`) see half of that - "
                               "fusion keeps the rest on chip - so the step is NOT HBM-bound at this size: like C2 it is "
                               "bound by MFMA/VALU issue, and `mfma.frac` (x3 for pipe occupancy: 3 passes per MAC) is the "
-                              "figure the counters support.  Kernels at 224x400 maps: profiles/r5_c5_kernel_summary.txt"}
+                              "figure the counters support.  Kernels at 224x400 maps: profiles/r6_c5_kernel_summary.txt"}
     out["C2_exact_fp32"] = measure(16, 448, 800, 0.01, exact_fp32=True, steps=6, warm=2)
     out["C2_single_frame_latency"] = measure(1, 448, 800, 0.01)
     out["C2_one_nuscenes_sample_bs6"] = measure(6, 448, 800, 0.01)     # the 6 cameras of one sample (detector.py:44-155)
