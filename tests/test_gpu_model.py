@@ -698,6 +698,29 @@ def test_two_lane_neck_equals_single_stream(dev, radar, B, H, W):
                 assert torch.equal(y[k], one[k]), k
 
 
+@pytest.mark.parametrize("radar,B,H,W", [(True, 1, 32, 32), (True, 5, 32, 96), (False, 2, 64, 32), (True, 1, 448, 128)])
+def test_smallest_legal_inputs_and_portrait_shapes(dev, radar, B, H, W):
+    """The smallest inputs the module accepts (H, W multiples of 32: level 5 is then a 1 x 1 .. 1 x 3 map, every kernel runs its
+    ragged-tile / tiny-grid paths) and a portrait one, against the oracle; the decode of the HIP maps equals the oracle's decode
+    of the SAME maps bit for bit (near-ties in the scores may order two arithmetics' own maps differently on maps this small)."""
+    from centerfusiondetect3d_amd import fusionDecode
+    sd = cases.tuned_state_dict(radar=radar, seed=0)
+    m = _model(radar, dev, (H, W))
+    x, pc_dep, calib = cases.model_inputs(B, H, W, seed=3, radar=radar, n_points=(2, 6))
+    K = min(100, 10 * (H // 4) * (W // 4))
+    with torch.no_grad():
+        y = m(x.to(dev), pc_dep=pc_dep.to(dev) if radar else None, calib=calib.to(dev))
+        ref = model_ref.forward(sd, x, pc_dep=pc_dep if radar else None, calib=calib, radar=radar)
+    for k, v in ref[0].items():
+        if k != "calib":
+            _assert_maps_close(y[0][k], v, k)
+    y_cpu = [{k: (v.cpu().clone() if torch.is_tensor(v) else v) for k, v in y[0].items()}]
+    det = fusionDecode(y, outputSize=(H // 4, W // 4), K=K)
+    det_ref = decode_ref.fusion_decode(y_cpu, (H // 4, W // 4), K)
+    for k in ("scores", "classIds", "centers", "bboxes"):
+        assert np.array_equal(det[k].cpu().numpy(), det_ref[k].numpy()), k
+
+
 def test_plan_cache_is_an_lru_and_frees_evicted_buffers(dev):
     """A service that sees varying batch sizes must not keep one plan set (every intermediate buffer of a forward) per
     size for ever: at most `max_plan_sets` (default 4) live, the least recently used set is dropped whole and its memory
