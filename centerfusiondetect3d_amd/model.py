@@ -391,7 +391,7 @@ class _Plan:
             children.append(x1)
             return tree(p + ".tree2", levels - 1, x1, 1, False, children)
 
-        def dcn_node(p, x, out=None):
+        def dcn_node(p, x, out=None, feat_producer=False):
             _, h, w, c = x.shape
             om = buf(B, h, w, 32)
             conv(p + ".conv_offset_mask", [x], h, w, act=ACT_NONE, out=om, out_stride=32)
@@ -404,15 +404,15 @@ class _Plan:
             a = ops.dcn_args(pd, x, om, 32, B, h, w, o, pd.n, ACT_RELU, precise=model.precise, workspace=ws,
                              in_scale=model._scale(p) if pd.out_scale > 0 else None)
             self.keep.append(a)
-            if out is not None:
-                self.feat_producer = a                       # the DCN that writes the feature map (ida(..., final_out=))
+            if feat_producer:
+                self.feat_producer = a                       # the DCN that writes the feature map (the last node of ida_up)
             self.inputs[p] = [x]
             self.step_index[p] = len(self.steps)
             self.step_flops[p] = 2.0 * B * h * w * pd.n * 9 * pd.c
             self.add_step((self.lib.cf_dcn_v2_f16x3 if pd.out_scale > 0 else self.lib.cf_dcn_v2_fused, C.byref(a)))
             return o
 
-        def ida(p, layers, startp, endp, final_out=None):
+        def ida(p, layers, startp, endp, final_out=None, feat=False):
             """IDAUp.forward (dla.py:518-524).  The projections of one IDA level read maps that all exist when the level
             starts and do not depend on each other or on the nodes, so with `self.use_lanes` they are issued on a side
             stream (offset conv + DCN per projection) while the caller's stream runs the node chain
@@ -440,7 +440,8 @@ class _Plan:
                 summed = buf(B, h * f, w * f, c)          # up(proj(x)) + skip, fused
                 self.add_step((self.lib.cf_upsample_dw, proj.data_ptr(), wk.data_ptr(),
                                layers[i - 1].data_ptr(), summed.data_ptr(), B, h, w, c, f))
-                layers[i] = dcn_node(f"{p}.node_{j}", summed, out=final_out if i == endp - 1 else None)
+                layers[i] = dcn_node(f"{p}.node_{j}", summed, out=final_out if i == endp - 1 else None,
+                                     feat_producer=feat and i == endp - 1)
 
         bf = model._heads_bf()                             # fused split-bf16 head launches (False: the exact-fp32 layer-by-layer heads)
         h4, w4 = H // 4, W // 4
@@ -486,7 +487,7 @@ class _Plan:
             for i, t in enumerate(out):
                 self.debug[f"up{i}"] = t
             y = out[:3]
-            ida("ida_up", y, 0, 3, final_out=feat)
+            ida("ida_up", y, 0, 3, final_out=feat, feat=True)
             feat = y[-1]
             if bf and model._mx_active:
                 # heads' first layer on fp16 + FP6 (cf_head_fused mx = 1): the 272-byte rows it stages, one pass over the
