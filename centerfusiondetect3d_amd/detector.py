@@ -28,7 +28,7 @@ FOCAL_LENGTH = 1200          # datasets/nuscenes.py:34 (used when an image has n
 
 
 class Detector(object):
-    def __init__(self, config, show=False, pause=False, *, model=None, device=None, range_policy="raise"):
+    def __init__(self, config, show=False, pause=False, *, model=None, device=None, range_policy="raise", range_check_every=0):
         """detector.py:21-42: `Detector(config, show=False, pause=False)` builds the model with `getModel(config)`
         and, when `config.MODEL.LOAD_DIR` is set (the reference's radar configs set it,
         configs/Centerfusion_Middle.yaml:43), loads that checkpoint with `loadModel` before `.to(device).eval()`.
@@ -41,10 +41,15 @@ class Detector(object):
         batch after the weights were loaded goes through the model's range guard: "raise" (default) = `model.check_ranges` -
         a `CfHipError` naming the layers if any input reaches half that limit, never a silently clamped map; "calibrate" =
         `model.calibrate` on that batch (per-layer power-of-two pre-scales; results unchanged bit for bit where no layer
-        needs one); "off" = no check.  `model.check_resident_ranges()` re-tests a running service at no extra forward."""
+        needs one); "off" = no check.  `range_check_every = N > 0` (with a policy other than "off"): every N-th batch the buffers
+        that batch's forward left in HBM are re-tested as well (`model.check_resident_ranges()`: one reduction per buffer and a
+        device -> host copy, ~2 ms at bs=16, no second forward; raises like the first-batch guard) - for a service whose inputs
+        may drift away from the batch it was checked or calibrated on."""
         if range_policy not in ("raise", "calibrate", "off"):
             raise ValueError("range_policy must be 'raise', 'calibrate' or 'off'")
         self.range_policy = range_policy
+        self.range_check_every = max(0, int(range_check_every))
+        self._batches = 0
         if not isinstance(show, bool) or not isinstance(pause, bool):
             raise TypeError("Detector(config, show=False, pause=False, *, model=None, device=None): "
                             "show / pause are booleans; pass a pre-built module as model=")
@@ -116,6 +121,9 @@ class Detector(object):
             # first batch on these weights: the range guard (one slow exact-fp32 forward; sets model._range_checked)
             (self.model.calibrate if self.range_policy == "calibrate" else self.model.check_ranges)(images, pc_dep, calibs)
         outputs = self.model(images, pc_dep=pc_dep, calib=calibs)
+        self._batches += 1
+        if self.range_policy != "off" and self.range_check_every and self._batches % self.range_check_every == 0:
+            self.model.check_resident_ranges()
         if mark is not None:
             mark("net")
         outH, outW = self.config.MODEL.OUTPUT_SIZE

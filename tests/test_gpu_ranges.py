@@ -289,3 +289,16 @@ def test_detector_first_batch_goes_through_the_guard(dev):
     assert not torch.equal(off["post"], ret["post"])                   # (the unguarded result is the clamped one)
     with pytest.raises(ValueError):
         Detector(cfg, model=getModel(cfg), device=dev, range_policy="maybe")
+    # a running service: inputs drift after the first batch was checked - the periodic re-test of the resident buffers sees it
+    model = getModel(cfg)
+    model.load_state_dict(cases.tuned_state_dict(radar=True, seed=0))
+    det = Detector(cfg, model=model, device=dev, range_policy="raise", range_check_every=2)
+    det.run(frames, infos, sweeps)                                     # batch 1: first-batch guard, fine
+    assert det.model._range_checked
+    with torch.no_grad():
+        for k, v in det.model.state_dict().items():                   # (stands for drifting inputs: the feature map grows 4096 x
+            if k.startswith("ida_up.node_2.activation.0.") and k.endswith((".weight", ".bias")):   #  without a reload of the weights)
+                v.mul_(4096.0)
+        det.model.invalidate()
+    with pytest.raises(_lib.CfHipError, match=r"check_resident_ranges.*heads\.primary\.0"):
+        det.run(frames, infos, sweeps)                                 # batch 2: every second batch is re-tested

@@ -217,7 +217,7 @@ def test_detector_constructor_is_the_references(tmp_path):
     ps = list(inspect.signature(Detector.__init__).parameters.values())
     assert [(p.name, p.default) for p in ps[:4]] == [("self", inspect.Parameter.empty),
                                                       ("config", inspect.Parameter.empty), ("show", False), ("pause", False)]
-    assert all(p.kind is inspect.Parameter.KEYWORD_ONLY for p in ps[4:]) and {p.name for p in ps[4:]} == {"model", "device", "range_policy"}
+    assert all(p.kind is inspect.Parameter.KEYWORD_ONLY for p in ps[4:]) and {p.name for p in ps[4:]} == {"model", "device", "range_policy", "range_check_every"}
     cfg = centerfusion_middle_config((64, 64))
     cfg.MODEL.LOAD_DIR = str(tmp_path / "no_such_checkpoint.pth")
     with pytest.raises(FileNotFoundError):
