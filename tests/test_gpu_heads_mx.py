@@ -54,10 +54,14 @@ def test_pack_feat_mx_rows_bit_exact(dev):
     assert np.array_equal(rows_w, ref)
 
 
-def _heads_case(dev, n_hidden, radar, B, H, W, n_outs=(10, 1, 3, 8), acts=(2, 3, 0, 0)):
+def _heads_case(dev, n_hidden, radar, B, H, W, n_outs=(10, 1, 3, 8), acts=(2, 3, 0, 0), denormals=False):
     from centerfusiondetect3d_amd import ops, packing
     feat, pch = F.relu(rnd(B, 64, H, W, seed=1)) * 3.0, rnd(B, 3, H, W, seed=2) * 20.0
     feat[:, :, 0, :3] = 0.0                                    # all-zero pixels (zero blocks inside the image)
+    if denormals:                                              # blocks whose maximum is an fp32 denormal / below 2^-125 (ADVICE r5:
+        feat[:, :32, 1, :] = 1e-39                             #  their E8M0 code must stay a number - never 255 = NaN - and the
+        feat[:, 32:, 2, :] = 2.0 ** -130                       #  head launch that reads them must stay finite)
+        feat[:, :, 3, 1] = torch.tensor([1e-39, 0.0] * 32)
     rows = ops.pack_feat_mx(nhwc(feat).to(dev))
     srcs = [rows] + ([ops.split_bf16(nhwc(pch).to(dev), cs=8)] if radar else [])
     ci = 67 if radar else 64
@@ -129,6 +133,22 @@ def test_head_fused_mx_whole_head(dev, n_hidden, radar, B, H, W):
         assert e_fp32 < 2e-4, e_fp32
         if hd["act"] == 3:
             torch.testing.assert_close(hd["out2"].cpu().double(), 1.0 / (torch.sigmoid(r64) + 1e-6) - 1.0, rtol=1e-3, atol=1e-3)
+
+
+def test_head_fused_mx_is_finite_on_denormal_blocks(dev):
+    """Feature blocks whose largest value is an fp32 denormal (or below 2^-125, where the block exponent would leave E8M0's
+    range): the pack kernel writes them as zero blocks with a valid scale byte, and the head launch that reads them stays
+    finite and equal to the oracle's evaluation of the same operands."""
+    from centerfusiondetect3d_amd import ops
+    f, heads, refs64, _ = _heads_case(dev, 0, True, 1, 8, 16, denormals=True)
+    rows = f._keep[0].cpu().numpy().reshape(-1, 272)
+    assert rows[:, 256:260].max() < 255
+    ops.run_head_fused(f)
+    for hd, r64 in zip(heads, refs64):
+        got = hd["out"].cpu().double()
+        assert bool(torch.isfinite(got).all())
+        if hd["act"] != 2:
+            assert float((got - r64).abs().max()) / float(r64.abs().max()) < 2e-5
 
 
 def test_head_fused_mx_refuses_what_it_cannot_read(dev):
