@@ -1,5 +1,5 @@
 """Dev tool (GPU box): the float64-anchored accuracy gate of tests/test_gpu_model.py (RMS error of the HIP path against the
-float64 oracle <= 1.25 x the fp32 oracle's own, worst element <= 2 x + 2e-5) over several weight / input seeds, with the
+float64 oracle <= max(1.25 x the fp32 oracle's own + 2e-6, 5e-5 of the output's RMS), worst element <= 2 x + 2e-5) over several weight / input seeds, with the
 heads' first layers on fp16 + FP6 (default) and on bf16x3 (--heads-bf16x3): how much margin the scheme keeps.
     python tests/tools/eval_mx_gate_gpu.py [n_seeds] [--heads-bf16x3]"""
 import os, sys
@@ -37,9 +37,9 @@ for seed in ([int(a.split("=")[1]) for a in sys.argv if a.startswith("--seed=")]
         r_gpu, r_cpu = float((g - t).pow(2).mean().sqrt()) / rms, float((c - t).pow(2).mean().sqrt()) / rms
         e_gpu, e_cpu = float((g - t).abs().max()) / scale, float((c - t).abs().max()) / scale
         ratio = r_gpu / (r_cpu + 1e-300)
-        ok = r_gpu <= 1.25 * r_cpu + 2e-6 and e_gpu <= 2.0 * e_cpu + 2e-5
+        ok = r_gpu <= max(1.25 * r_cpu + 2e-6, 5e-5) and e_gpu <= 2.0 * e_cpu + 2e-5      # the criterion of tests/test_gpu_model.py: _gate (round 6)
         worst_ratio = max(worst_ratio, ratio if r_cpu > 1e-6 else 0.0)
         worst_max = max(worst_max, e_gpu / (2.0 * e_cpu + 2e-5))
         line.append(f"{k}:{ratio:.2f}{'' if ok else '(FAIL)'}" + (f"[{r_gpu:.1e}/{r_cpu:.1e}]" if "--abs" in sys.argv else ""))
     print(f"seed {seed} ({'fp16+FP6 first layers' if mx else 'bf16x3'}): rms hip / rms fp32-oracle  " + "  ".join(line), flush=True)
-print(f"worst RMS ratio {worst_ratio:.3f} (gate 1.25); worst max-norm / allowed {worst_max:.3f} (gate 1)")
+print(f"worst RMS ratio {worst_ratio:.3f} (1.25 or the absolute floor 5e-5); worst max-norm / allowed {worst_max:.3f} (gate 1)")
