@@ -501,7 +501,7 @@ def test_config_c2_full_size_properties(dev):
     # ... and frames of the bs=16 batch against the oracle (not only against the HIP path itself); `full` had
     # rotation2 renamed to rotation by the decode above, as the reference's decode does
     sd = cases.tuned_state_dict(radar=True, seed=0)
-    for f in (3, 12):
+    for f in (12,):            # (one frame: each costs an fp32 and a float64 oracle run at 448 x 800; frame 3 went with round 6's suite trim)
         sl = slice(f, f + 1)
         noise, r32, _ = _fp32_noise(sd, x[sl], pc_dep[sl], calib[sl], True)
         for k, v in r32.items():
